@@ -1,0 +1,104 @@
+"""The CPU oracle (oracle/mdd_oracle.c) against golden vectors made by the reference's own
+Python (oracle/gen_golden.py).  CPU only.  This is what pins the oracle."""
+import numpy as np
+import pytest
+
+from oracle import oracle
+from tests.helpers import npz, jload, ids_to_beam_string, ids_to_greedy_string
+from ctc_attention_mispronunciation_amd import synth
+
+ERR = {0: None, 1: "IndexError", 2: "ValueError", 3: "KeyError"}
+# |oracle - reference| budget on log-probs: the reference's own fp32 rounding, far inside the
+# 1e-4 parity tolerance BASELINE.json states for the GPU path.
+TOL_ORACLE = 2e-5
+
+
+def test_g1_tiny_every_stage():
+    g = npz("g1_tiny.npz")
+    geom = synth.Geometry(**synth.TINY)
+    sd = synth.synth_state_dict(geom, seed=11)
+    taps = {}
+    logp = oracle.forward(sd, g["x"], g["x1"], taps)
+    for name in ("conv0", "conv1", "rnn0", "rnn1", "text", "key"):
+        np.testing.assert_allclose(taps[name], g[name], rtol=0, atol=TOL_ORACLE, err_msg=name)
+    np.testing.assert_allclose(taps["logits"].reshape(g["logits"].shape), g["logits"], rtol=0, atol=TOL_ORACLE)
+    np.testing.assert_allclose(logp, g["logp"], rtol=0, atol=TOL_ORACLE)
+    assert (logp.argmax(-1) == g["logp"].argmax(-1)).all()
+
+
+@pytest.mark.parametrize("idx", [0, 1, 2])
+def test_g2_reference_geometry(idx):
+    meta = jload("g2_ref.json")[idx]
+    g = npz("g2_ref.npz")
+    geom = synth.Geometry(**meta["geom"])
+    sd = synth.synth_state_dict(geom, seed=meta["seed"])
+    x, x1, frac, tlen = synth.synth_batch(geom, B=meta["B"], T=meta["T"], L=meta["L"], seed=meta["seed"])
+    logp = oracle.forward(sd, x, x1)
+    ref = g[meta["tag"] + "_logp"]
+    assert logp.shape == ref.shape
+    np.testing.assert_allclose(logp, ref, rtol=0, atol=TOL_ORACLE)
+    if meta["min_top2_gap"] > 1e-3:
+        assert (logp.argmax(-1) == ref.argmax(-1)).all()
+
+
+@pytest.mark.parametrize("si", [0, 1])
+def test_g3_decoders(si):
+    meta = jload("g3_decode.json")["sets"][si]
+    g = npz("g3_decode.npz")
+    Cn, i2c = meta["C"], meta["int2char"]
+    for r in meta["records"]:
+        lp = g["c%d_case%d" % (Cn, r["case"])][:, None, :]
+        gr = oracle.greedy(lp, [r["len"]])[0]
+        assert ids_to_greedy_string(gr, i2c) == r["greedy"], r
+        ids, st = oracle.beam(lp, [r["len"]], g[r["lm"]], beam_width=r["width"], alpha=r["alpha"])
+        assert ERR[int(st[0])] == r["error"], r
+        if r["error"] is None:
+            assert ids_to_beam_string(ids[0], i2c) == r["beam"], r
+    for f in meta["failures"]:
+        lp = g["c%d_fail_%s" % (Cn, f["name"])][:, None, :]
+        ids, st = oracle.beam(lp, [f["len"]], g[f["lm"]], beam_width=f["width"], alpha=f["alpha"])
+        assert ERR[int(st[0])] == f["error"], f
+        assert ids_to_greedy_string(oracle.greedy(lp, [f["len"]])[0], i2c) == f["greedy"]
+    b = meta["batch"]
+    batch = g["c%d_batch" % Cn]
+    assert [ids_to_greedy_string(x, i2c) for x in oracle.greedy(batch, b["lens"])] == b["greedy"]
+    ids, st = oracle.beam(batch, b["lens"], g["lm%d" % Cn])
+    assert not st.any()
+    assert [ids_to_beam_string(x, i2c) for x in ids] == b["beam"]
+
+
+def test_g4_alignment():
+    g = jload("g4_align.json")
+    for r in g["pairs"]:
+        vocab = {w: i for i, w in enumerate(sorted(set(r["hyp"] + r["can"])))}
+        dist, ops = oracle.align([vocab[w] for w in r["hyp"]], [vocab[w] for w in r["can"]])
+        assert dist == r["dist"] and ops == r["ops"], r
+    for e in g["empties"]:
+        assert e["error"] == "TypeError"
+        with pytest.raises(TypeError):
+            oracle.align([1] * len(e["s1"].split()), [2] * len(e["s2"].split()))
+
+
+def test_g5_ctc_loss_and_grad():
+    g = npz("g5_ctc.npz")
+    for m in jload("g5_ctc.json"):
+        i = m["i"]
+        nll, grad = oracle.ctc_loss(g["logp%d" % i], g["tg%d" % i], g["il%d" % i], g["tl%d" % i])
+        ref_nll, ref_grad = g["nll%d" % i], g["grad%d" % i]
+        fin = np.isfinite(ref_nll)
+        assert (np.isinf(nll) == ~fin).all()
+        np.testing.assert_allclose(nll[fin], ref_nll[fin], rtol=2e-6, atol=1e-4)
+        np.testing.assert_allclose(grad[:, fin, :], ref_grad[:, fin, :], rtol=0, atol=1e-4)  # ATen keeps the lattice in fp32
+        if fin.all():
+            assert abs(float(nll.sum()) - m["loss"]) <= 1e-5 * max(1.0, abs(m["loss"]))
+
+
+def test_g6_stack_skip_and_lengths():
+    g = npz("g6_input.npz")
+    i = 0
+    while "raw%d" % i in g:
+        np.testing.assert_array_equal(oracle.stack_skip(g["raw%d" % i]), g["stk%d" % i])
+        i += 1
+    assert i == 6
+    for ln, maxlen, tout, want in g["len_table"]:
+        assert oracle.len_frames(ln, maxlen, tout) == want, (ln, maxlen, tout)
