@@ -1,0 +1,433 @@
+// C-ABI of libmdd_hip.so: handle, weights, workspace, forward orchestration (include/mdd_hip.h).
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <cmath>
+
+#include "mdd_internal.h"
+
+namespace mdd {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+struct DevBuf {
+    float *p = nullptr;
+    size_t cap = 0;  // in floats
+};
+
+struct GraphKey {
+    const void *x, *x1, *out;
+    int B, T, L;
+    hipStream_t st;
+    bool operator<(const GraphKey &o) const { return memcmp(this, &o, sizeof(GraphKey)) < 0; }
+};
+
+}  // namespace mdd
+
+struct mdd_model {
+    mdd_config cfg;
+    int device = 0;
+    bool finalized = false, taps = false, use_graph = true;
+    std::map<std::string, std::vector<float>> host;  // state_dict entries as loaded
+    // device weights
+    float *w_conv0 = nullptr, *sc0 = nullptr, *sh0 = nullptr;
+    float *w_conv1t = nullptr, *sc1 = nullptr, *sh1 = nullptr;
+    std::vector<float *> wih, whh, bn_scale, bn_shift;  // per rnn layer (bn_* of layer n applies to layer n's INPUT)
+    float *emb = nullptr, *t_wih = nullptr, *t_whh = nullptr, *t_bias = nullptr;
+    float *w_score = nullptr, *fscale = nullptr, *fshift = nullptr, *w_fc = nullptr;
+    std::vector<void *> owned;  // every hipMalloc'd weight pointer
+    // workspace
+    mdd::DevBuf y0, seq0, gx, act[2], xraw, hbuf, cbuf, embo, text, key, S;
+    std::vector<mdd::DevBuf> tap_rnn;
+    int *err_flag = nullptr;
+    int lastB = 0, lastT = 0, lastL = 0;
+    std::map<mdd::GraphKey, hipGraphExec_t> graphs;
+    int W1() const { return (cfg.feat + 2 - 3) / 2 + 1; }
+    int W2() const { return (W1() + 2 - 3) / 2 + 1; }
+    int rnn_in() const { return cfg.channels * W2(); }
+};
+
+namespace mdd {
+
+static int upload(mdd_model *m, const std::vector<float> &h, float **dev) {
+    MDD_HIP_CHECK(hipMalloc((void **)dev, h.size() * sizeof(float)));
+    m->owned.push_back(*dev);
+    MDD_HIP_CHECK(hipMemcpy(*dev, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice));
+    return MDD_OK;
+}
+
+static bool g_ws_moved = false;  // a workspace buffer was reallocated: captured graphs hold stale pointers
+
+static int ensure(DevBuf &b, size_t n) {
+    if (b.cap >= n) return MDD_OK;
+    g_ws_moved = true;
+    if (b.p) MDD_HIP_CHECK(hipFree(b.p));
+    b.p = nullptr; b.cap = 0;
+    MDD_HIP_CHECK(hipMalloc((void **)&b.p, n * sizeof(float)));
+    b.cap = n;
+    return MDD_OK;
+}
+
+static const std::vector<float> *get(mdd_model *m, const std::string &key, size_t numel) {
+    auto it = m->host.find(key);
+    if (it == m->host.end()) { set_error("weight '%s' was never loaded", key.c_str()); return nullptr; }
+    if (it->second.size() != numel) {
+        set_error("weight '%s' has %zu elements, expected %zu", key.c_str(), it->second.size(), numel);
+        return nullptr;
+    }
+    return &it->second;
+}
+
+// eval-mode BatchNorm as y = x*scale + shift
+static bool bn_fold(mdd_model *m, const std::string &prefix, int n, std::vector<float> &scale, std::vector<float> &shift) {
+    const auto *w = get(m, prefix + ".weight", n), *b = get(m, prefix + ".bias", n);
+    const auto *mu = get(m, prefix + ".running_mean", n), *var = get(m, prefix + ".running_var", n);
+    if (!w || !b || !mu || !var) return false;
+    scale.resize(n); shift.resize(n);
+    for (int i = 0; i < n; i++) {
+        scale[i] = (*w)[i] / sqrtf((*var)[i] + m->cfg.bn_eps);
+        shift[i] = (*b)[i] - (*mu)[i] * scale[i];
+    }
+    return true;
+}
+
+// rows n = g*H + u  ->  n' = u*4 + g (see lstm.hip); concatenates the two directions
+static bool pack_gate_rows(mdd_model *m, const std::string &base, const char *what, int H, int K, std::vector<float> &out) {
+    out.assign((size_t)2 * 4 * H * K, 0.f);
+    for (int d = 0; d < 2; d++) {
+        const auto *w = get(m, base + what + (d ? "_reverse" : ""), (size_t)4 * H * K);
+        if (!w) return false;
+        for (int g = 0; g < 4; g++)
+            for (int u = 0; u < H; u++)
+                memcpy(&out[((size_t)d * 4 * H + u * 4 + g) * K], &(*w)[((size_t)g * H + u) * K], sizeof(float) * K);
+    }
+    return true;
+}
+
+static int forward_enqueue(mdd_model *m, const float *x, int B, int T, const int64_t *x1, int L, float *logp, hipStream_t st) {
+    const mdd_config &c = m->cfg;
+    const int H = c.hidden, H2 = 2 * H, G2 = 8 * H, Tp = T / 2, Lp = L;
+    int rc;
+    if ((rc = launch_conv0(x, m->w_conv0, m->sc0, m->sh0, m->y0.p, B, T, c.feat, c.channels, st))) return rc;
+    if ((rc = launch_conv1(m->y0.p, m->w_conv1t, m->sc1, m->sh1, m->seq0.p, B, T, m->W1(), c.channels, st))) return rc;
+    const float *in = m->seq0.p;
+    int K = m->rnn_in();
+    for (int n = 0; n < c.layers; n++) {
+        if ((rc = launch_gemm_nt(in, m->wih[n], nullptr, m->gx.p, Tp * B, G2, K, K, K, G2, 1, 0, 0, 0, st))) return rc;
+        const bool lastl = (n == c.layers - 1);
+        LstmStepArgs a;
+        a.gx = m->gx.p; a.whh = m->whh[n]; a.hbuf = m->hbuf.p; a.cbuf = m->cbuf.p;
+        a.T = Tp; a.B = B; a.H = H;
+        if (lastl) { a.out = m->xraw.p; a.out_raw = m->xraw.p; a.oscale = nullptr; a.oshift = nullptr; }
+        else {
+            a.out = m->act[n & 1].p; a.out_raw = m->taps ? m->tap_rnn[n].p : nullptr;
+            a.oscale = m->bn_scale[n + 1]; a.oshift = m->bn_shift[n + 1];
+        }
+        if ((rc = launch_lstm_layer(a, st))) return rc;
+        in = m->act[n & 1].p;
+        K = H2;
+    }
+    // text encoder (model_ctc.py:193,198) and keys (:201)
+    if ((rc = launch_embed(m->emb, c.emb_rows, c.emb_dim, x1, B, L, m->embo.p, m->err_flag, st))) return rc;
+    if ((rc = launch_gemm_nt(m->embo.p, m->t_wih, m->t_bias, m->gx.p, L * B, G2, c.emb_dim, c.emb_dim, c.emb_dim, G2, 1, 0, 0, 0, st))) return rc;
+    {
+        LstmStepArgs a;
+        a.gx = m->gx.p; a.whh = m->t_whh; a.hbuf = m->hbuf.p; a.cbuf = m->cbuf.p;
+        a.out = m->text.p; a.out_raw = m->text.p; a.oscale = nullptr; a.oshift = nullptr;
+        a.T = L; a.B = B; a.H = H;
+        if ((rc = launch_lstm_layer(a, st))) return rc;
+    }
+    if ((rc = launch_gemm_nt(m->text.p, m->w_score, nullptr, m->key.p, L * B, H2, H2, H2, H2, H2, 1, 0, 0, 0, st))) return rc;
+    // scores S[b][t][l] = X[t,b,:] . key[l,b,:]   (:204)
+    if ((rc = launch_gemm_nt(m->xraw.p, m->key.p, nullptr, m->S.p, Tp, L, H2, B * H2, B * H2, Lp, B, H2, H2, (long)Tp * Lp, st))) return rc;
+    return launch_attn_tail(m->S.p, Lp, m->xraw.p, m->text.p, m->fscale, m->fshift, m->w_fc, logp, Tp, B, L, H2, c.num_class, st);
+}
+
+}  // namespace mdd
+
+using namespace mdd;
+
+extern "C" const char *mdd_last_error(void) { return g_err; }
+extern "C" int mdd_version(void) { return 100; }
+
+extern "C" int mdd_create(const mdd_config *cfg, int device, mdd_model **out) {
+    if (!cfg || !out) { set_error("mdd_create: null argument"); return MDD_ERR_ARG; }
+    if (cfg->hidden <= 0 || cfg->hidden % 4 || cfg->layers < 1 || cfg->num_class < 2 || cfg->feat < 3 ||
+        (cfg->channels != 32 && cfg->channels != 4) || cfg->emb_rows < 1 || cfg->emb_dim < 1) {
+        set_error("mdd_create: unsupported geometry (hidden %% 4 == 0, channels in {32,4})");
+        return MDD_ERR_ARG;
+    }
+    int ndev = 0;
+    MDD_HIP_CHECK(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev) { set_error("mdd_create: device %d of %d", device, ndev); return MDD_ERR_ARG; }
+    MDD_HIP_CHECK(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    MDD_HIP_CHECK(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        set_error("libmdd_hip is built for gfx950 (MI355X) only; device %d is %s", device, prop.gcnArchName);
+        return MDD_ERR_ARG;
+    }
+    mdd_model *m = new mdd_model();
+    m->cfg = *cfg;
+    m->device = device;
+    const char *g = getenv("MDD_GRAPH");
+    m->use_graph = !(g && g[0] == '0');
+    if (int rc = init_kernel_attributes()) { delete m; return rc; }
+    hipError_t e = hipMalloc((void **)&m->err_flag, sizeof(int));
+    if (e == hipSuccess) e = hipMemset(m->err_flag, 0, sizeof(int));
+    if (e != hipSuccess) { set_error("mdd_create: %s", hipGetErrorString(e)); delete m; return MDD_ERR_HIP; }
+    *out = m;
+    return MDD_OK;
+}
+
+extern "C" void mdd_destroy(mdd_model *m) {
+    if (!m) return;
+    (void)hipSetDevice(m->device);
+    (void)hipDeviceSynchronize();
+    for (auto &kv : m->graphs) (void)hipGraphExecDestroy(kv.second);
+    for (void *p : m->owned) (void)hipFree(p);
+    DevBuf *bufs[] = {&m->y0, &m->seq0, &m->gx, &m->act[0], &m->act[1], &m->xraw, &m->hbuf, &m->cbuf, &m->embo, &m->text, &m->key, &m->S};
+    for (DevBuf *b : bufs) if (b->p) (void)hipFree(b->p);
+    for (auto &b : m->tap_rnn) if (b.p) (void)hipFree(b.p);
+    if (m->err_flag) (void)hipFree(m->err_flag);
+    delete m;
+}
+
+extern "C" int mdd_load_weight(mdd_model *m, const char *key, const float *data, const int64_t *shape, int32_t ndim) {
+    if (!m || !key || (!data && ndim > 0) || ndim < 0 || ndim > 4) { set_error("mdd_load_weight: bad argument"); return MDD_ERR_ARG; }
+    std::string k(key);
+    if (k.size() > 19 && k.compare(k.size() - 19, 19, "num_batches_tracked") == 0) return MDD_OK;  // unused in eval
+    size_t n = 1;
+    for (int i = 0; i < ndim; i++) { if (shape[i] < 0) { set_error("negative dim"); return MDD_ERR_ARG; } n *= (size_t)shape[i]; }
+    m->host[k].assign(data, data + n);
+    m->finalized = false;
+    return MDD_OK;
+}
+
+extern "C" int mdd_finalize_weights(mdd_model *m) {
+    if (!m) { set_error("null model"); return MDD_ERR_ARG; }
+    MDD_HIP_CHECK(hipSetDevice(m->device));
+    const mdd_config &c = m->cfg;
+    const int ch = c.channels, H = c.hidden;
+    int rc;
+    for (void *p : m->owned) (void)hipFree(p);
+    m->owned.clear(); m->wih.clear(); m->whh.clear();
+    m->bn_scale.assign(c.layers, nullptr); m->bn_shift.assign(c.layers, nullptr);
+    for (auto &kv : m->graphs) (void)hipGraphExecDestroy(kv.second);
+    m->graphs.clear();
+    std::vector<float> sc, sh, tmp;
+    {   // conv0 / conv1: fold bias + BN into scale/shift; conv1 weights -> [ci][kh][kw][co]
+        const auto *w0 = get(m, "conv.0.conv.weight", (size_t)ch * 9), *b0 = get(m, "conv.0.conv.bias", ch);
+        const auto *w1 = get(m, "conv.1.conv.weight", (size_t)ch * ch * 9), *b1 = get(m, "conv.1.conv.bias", ch);
+        if (!w0 || !b0 || !w1 || !b1) return MDD_ERR_STATE;
+        if (!bn_fold(m, "conv.0.batch_norm", ch, sc, sh)) return MDD_ERR_STATE;
+        for (int i = 0; i < ch; i++) sh[i] += (*b0)[i] * sc[i];
+        if ((rc = upload(m, *w0, &m->w_conv0)) || (rc = upload(m, sc, &m->sc0)) || (rc = upload(m, sh, &m->sh0))) return rc;
+        if (!bn_fold(m, "conv.1.batch_norm", ch, sc, sh)) return MDD_ERR_STATE;
+        for (int i = 0; i < ch; i++) sh[i] += (*b1)[i] * sc[i];
+        tmp.assign((size_t)ch * 9 * ch, 0.f);
+        for (int co = 0; co < ch; co++)
+            for (int ci = 0; ci < ch; ci++)
+                for (int k = 0; k < 9; k++) tmp[((size_t)ci * 9 + k) * ch + co] = (*w1)[((size_t)co * ch + ci) * 9 + k];
+        if ((rc = upload(m, tmp, &m->w_conv1t)) || (rc = upload(m, sc, &m->sc1)) || (rc = upload(m, sh, &m->sh1))) return rc;
+    }
+    for (int n = 0; n < c.layers; n++) {
+        char base[64];
+        snprintf(base, sizeof(base), "rnns.%d.rnn.", n);
+        const int K = n == 0 ? m->rnn_in() : 2 * H;
+        float *d = nullptr;
+        if (!pack_gate_rows(m, base, "weight_ih_l0", H, K, tmp)) return MDD_ERR_STATE;
+        if ((rc = upload(m, tmp, &d))) return rc;
+        m->wih.push_back(d);
+        if (!pack_gate_rows(m, base, "weight_hh_l0", H, H, tmp)) return MDD_ERR_STATE;
+        if ((rc = upload(m, tmp, &d))) return rc;
+        m->whh.push_back(d);
+        if (n > 0) {
+            snprintf(base, sizeof(base), "rnns.%d.batch_norm", n);
+            if (!bn_fold(m, base, 2 * H, sc, sh)) return MDD_ERR_STATE;
+            if ((rc = upload(m, sc, &m->bn_scale[n])) || (rc = upload(m, sh, &m->bn_shift[n]))) return rc;
+        }
+    }
+    {   // text encoder: bias_ih + bias_hh folded into the input projection's epilogue
+        const auto *e = get(m, "embeds.weight", (size_t)c.emb_rows * c.emb_dim);
+        if (!e) return MDD_ERR_STATE;
+        if ((rc = upload(m, *e, &m->emb))) return rc;
+        if (!pack_gate_rows(m, "lstm_embeds.", "weight_ih_l0", H, c.emb_dim, tmp)) return MDD_ERR_STATE;
+        if ((rc = upload(m, tmp, &m->t_wih))) return rc;
+        if (!pack_gate_rows(m, "lstm_embeds.", "weight_hh_l0", H, H, tmp)) return MDD_ERR_STATE;
+        if ((rc = upload(m, tmp, &m->t_whh))) return rc;
+        std::vector<float> bi, bh;
+        if (!pack_gate_rows(m, "lstm_embeds.", "bias_ih_l0", H, 1, bi) || !pack_gate_rows(m, "lstm_embeds.", "bias_hh_l0", H, 1, bh)) return MDD_ERR_STATE;
+        for (size_t i = 0; i < bi.size(); i++) bi[i] += bh[i];
+        if ((rc = upload(m, bi, &m->t_bias))) return rc;
+    }
+    {
+        const auto *ws = get(m, "score.weight", (size_t)4 * H * H), *wf = get(m, "fc.1.weight", (size_t)c.num_class * 4 * H);
+        if (!ws || !wf) return MDD_ERR_STATE;
+        if (!bn_fold(m, "fc.0", 4 * H, sc, sh)) return MDD_ERR_STATE;
+        if ((rc = upload(m, *ws, &m->w_score)) || (rc = upload(m, *wf, &m->w_fc)) || (rc = upload(m, sc, &m->fscale)) ||
+            (rc = upload(m, sh, &m->fshift))) return rc;
+    }
+    MDD_HIP_CHECK(hipDeviceSynchronize());
+    m->finalized = true;
+    return MDD_OK;
+}
+
+extern "C" int mdd_enable_taps(mdd_model *m, int32_t on) {
+    if (!m) return MDD_ERR_ARG;
+    m->taps = on != 0;
+    for (auto &kv : m->graphs) (void)hipGraphExecDestroy(kv.second);
+    m->graphs.clear();
+    return MDD_OK;
+}
+
+extern "C" int32_t mdd_stack_len(int32_t T_raw, int32_t skip, int32_t n_down) {
+    int kept = (skip <= 1) ? T_raw : (T_raw + skip - 1) / skip;
+    if (n_down > 1 && kept % n_down) kept += n_down - kept % n_down;
+    return kept;
+}
+
+extern "C" int mdd_stack_skip(const float *raw_dev, int32_t B, int32_t T_raw, int32_t D, int32_t right, int32_t skip,
+                              int32_t n_down, float *out_dev, void *stream) {
+    if (!raw_dev || !out_dev) { set_error("mdd_stack_skip: null pointer"); return MDD_ERR_ARG; }
+    return launch_stack_skip(raw_dev, B, T_raw, D, right, skip, n_down, out_dev, (hipStream_t)stream);
+}
+
+extern "C" int32_t mdd_len_frames(int32_t len, int32_t maxlen, int32_t t_out) {
+    // float32 fraction (data_loader.py:177) times T_out in float32, truncated (infer.py:296-297)
+    volatile float frac = (float)((double)len / (double)maxlen);
+    volatile float prod = frac * (float)t_out;
+    return (int32_t)prod;
+}
+
+extern "C" int mdd_forward(mdd_model *m, const float *x_dev, int32_t B, int32_t T, const int64_t *x1_dev, int32_t L,
+                           float *logp_dev, void *stream) {
+    if (!m || !x_dev || !x1_dev || !logp_dev) { set_error("mdd_forward: null pointer"); return MDD_ERR_ARG; }
+    if (!m->finalized) { set_error("mdd_forward: call mdd_finalize_weights first"); return MDD_ERR_STATE; }
+    if (B <= 0 || T < 2 || L <= 0) { set_error("mdd_forward: bad shape B=%d T=%d L=%d", B, T, L); return MDD_ERR_ARG; }
+    MDD_HIP_CHECK(hipSetDevice(m->device));
+    hipStream_t st = (hipStream_t)stream;
+    const mdd_config &c = m->cfg;
+    const int H = c.hidden, Tp = (T + 2 - 3) / 2 + 1;  // conv1 time stride 2, pad 1, k 3
+    if (T % 2) { set_error("mdd_forward: T must be even (data_loader.py:140-142 pads to n_downsample)"); return MDD_ERR_ARG; }
+    int rc;
+    const size_t rows = (size_t)Tp * B, trows = (size_t)L * B, mrows = rows > trows ? rows : trows;
+    if ((rc = ensure(m->y0, (size_t)B * c.channels * T * m->W1())) || (rc = ensure(m->seq0, rows * m->rnn_in())) ||
+        (rc = ensure(m->gx, mrows * 8 * H)) || (rc = ensure(m->act[0], rows * 2 * H)) || (rc = ensure(m->act[1], rows * 2 * H)) ||
+        (rc = ensure(m->xraw, rows * 2 * H)) || (rc = ensure(m->hbuf, (size_t)4 * B * H)) || (rc = ensure(m->cbuf, (size_t)2 * B * H)) ||
+        (rc = ensure(m->embo, trows * c.emb_dim)) || (rc = ensure(m->text, trows * 2 * H)) || (rc = ensure(m->key, trows * 2 * H)) ||
+        (rc = ensure(m->S, (size_t)B * Tp * L)))
+        return rc;
+    if (m->taps) {
+        m->tap_rnn.resize(c.layers);
+        for (int n = 0; n + 1 < c.layers; n++) if ((rc = ensure(m->tap_rnn[n], rows * 2 * H))) return rc;
+    }
+    m->lastB = B; m->lastT = T; m->lastL = L;
+    if (g_ws_moved) {
+        for (auto &kv : m->graphs) (void)hipGraphExecDestroy(kv.second);
+        m->graphs.clear();
+        g_ws_moved = false;
+    }
+    if (!m->use_graph) return forward_enqueue(m, x_dev, B, T, x1_dev, L, logp_dev, st);
+
+    GraphKey key;
+    memset(&key, 0, sizeof(key));
+    key.x = x_dev; key.x1 = x1_dev; key.out = logp_dev; key.B = B; key.T = T; key.L = L; key.st = st;
+    auto it = m->graphs.find(key);
+    if (it == m->graphs.end()) {
+        if (m->graphs.size() >= 8) { for (auto &kv : m->graphs) (void)hipGraphExecDestroy(kv.second); m->graphs.clear(); }
+        hipGraph_t graph = nullptr;
+        MDD_HIP_CHECK(hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed));
+        rc = forward_enqueue(m, x_dev, B, T, x1_dev, L, logp_dev, st);
+        hipError_t e = hipStreamEndCapture(st, &graph);
+        if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+        if (e != hipSuccess) { set_error("graph capture failed: %s", hipGetErrorString(e)); return MDD_ERR_HIP; }
+        hipGraphExec_t exec = nullptr;
+        e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(graph);
+        if (e != hipSuccess) { set_error("graph instantiate failed: %s", hipGetErrorString(e)); return MDD_ERR_HIP; }
+        it = m->graphs.emplace(key, exec).first;
+    }
+    MDD_HIP_CHECK(hipGraphLaunch(it->second, st));
+    return MDD_OK;
+}
+
+extern "C" const float *mdd_tap(mdd_model *m, const char *name, int64_t *numel) {
+    if (!m || !name || !m->lastB) return nullptr;
+    const int Tp = m->lastT / 2, B = m->lastB, L = m->lastL, H2 = 2 * m->cfg.hidden;
+    std::string n(name);
+    const float *p = nullptr;
+    int64_t ne = 0;
+    if (n == "conv1") { p = m->seq0.p; ne = (int64_t)Tp * B * m->rnn_in(); }
+    else if (n == "text") { p = m->text.p; ne = (int64_t)L * B * H2; }
+    else if (n == "key") { p = m->key.p; ne = (int64_t)L * B * H2; }
+    else if (n.compare(0, 3, "rnn") == 0) {
+        int i = atoi(n.c_str() + 3);
+        if (i == m->cfg.layers - 1) { p = m->xraw.p; ne = (int64_t)Tp * B * H2; }
+        else if (m->taps && i >= 0 && i < (int)m->tap_rnn.size()) { p = m->tap_rnn[i].p; ne = (int64_t)Tp * B * H2; }
+    }
+    if (numel) *numel = ne;
+    return p;
+}
+
+extern "C" int mdd_tap_copy(mdd_model *m, const char *name, float *dst_dev, int64_t capacity, void *stream) {
+    int64_t n = 0;
+    const float *p = mdd_tap(m, name, &n);
+    if (!p || !dst_dev) { set_error("mdd_tap_copy: no tap named '%s' (taps enabled?)", name ? name : "(null)"); return MDD_ERR_ARG; }
+    if (capacity < n) { set_error("mdd_tap_copy: capacity %lld < %lld", (long long)capacity, (long long)n); return MDD_ERR_ARG; }
+    MDD_HIP_CHECK(hipMemcpyAsync(dst_dev, p, (size_t)n * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return MDD_OK;
+}
+
+extern "C" int mdd_sync(mdd_model *m, void *stream) {
+    if (!m) { set_error("null model"); return MDD_ERR_ARG; }
+    MDD_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
+    int flag = 0;
+    MDD_HIP_CHECK(hipMemcpy(&flag, m->err_flag, sizeof(int), hipMemcpyDeviceToHost));
+    if (flag) {
+        MDD_HIP_CHECK(hipMemset(m->err_flag, 0, sizeof(int)));
+        set_error("index out of range in self");  // the message of the IndexError nn.Embedding raises
+        return MDD_ERR_ARG;
+    }
+    return MDD_OK;
+}
+
+// A10 -- host side, pure integer work on <= ~50 tokens per utterance
+extern "C" int mdd_align(const int32_t *a, int32_t na, const int32_t *b, int32_t nb, int32_t *dist, uint8_t *ops,
+                         int32_t *nops) {
+    if (na < 0 || nb < 0 || !dist || !ops || !nops) { set_error("mdd_align: bad argument"); return MDD_ERR_ARG; }
+    if (na == 0 || nb == 0) { set_error("mdd_align: empty sequence"); return MDD_ERR_EMPTY; }
+    const int W = nb + 1;
+    std::vector<int> d((size_t)(na + 1) * W);
+    for (int j = 0; j <= nb; j++) d[j] = j;
+    for (int i = 1; i <= na; i++) d[(size_t)i * W] = i;
+    for (int i = 1; i <= na; i++)
+        for (int j = 1; j <= nb; j++) {
+            const int sub = d[(size_t)(i - 1) * W + j - 1] + (a[i - 1] == b[j - 1] ? 0 : 1);
+            const int up = d[(size_t)(i - 1) * W + j] + 1, left = d[(size_t)i * W + j - 1] + 1;
+            int mn = left < up ? left : up;
+            d[(size_t)i * W + j] = sub < mn ? sub : mn;
+        }
+    *dist = d[(size_t)na * W + nb];
+    // backtrace priority: match > S (diagonal) > I (consumes hypothesis) > D (consumes canonical)
+    int i = na, j = nb, n = 0;
+    while (i > 0 || j > 0) {
+        if (i == 0) { ops[n++] = 3; j--; }
+        else if (j == 0) { ops[n++] = 2; i--; }
+        else if (a[i - 1] == b[j - 1]) { ops[n++] = 0; i--; j--; }
+        else if (d[(size_t)i * W + j] == d[(size_t)(i - 1) * W + j - 1] + 1) { ops[n++] = 1; i--; j--; }
+        else if (d[(size_t)i * W + j] == d[(size_t)(i - 1) * W + j] + 1) { ops[n++] = 2; i--; }
+        else { ops[n++] = 3; j--; }
+    }
+    for (int k = 0; k < n / 2; k++) { uint8_t t = ops[k]; ops[k] = ops[n - 1 - k]; ops[n - 1 - k] = t; }
+    *nops = n;
+    return MDD_OK;
+}

@@ -1,0 +1,129 @@
+/*
+ * mdd_hip.h -- C ABI of libmdd_hip.so: the MI355X (gfx950) implementation of the
+ * CTC-attention mispronunciation-detection hot path.
+ *
+ * The reference (dyustc/CTC-Attention-Mispronunciation, egs/attention_aug = "AA") has no FFI
+ * layer: its seam is Python objects.  Each entry point below names the reference interface it
+ * replaces; INTEGRATION.md shows the ctypes binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no C++ or torch types cross the boundary
+ *   - pointers named *_dev are device (HBM) addresses, everything else is host memory
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream); all GPU work is
+ *     enqueued on it and nothing synchronises unless a function says so
+ *   - every function returns 0 on success or a negative mdd_status; mdd_last_error() gives text
+ *   - a handle is not thread-safe: one handle per host thread / stream / device
+ *   - the caller owns every buffer it passes; the library owns device weights and a workspace
+ *     that grows on demand (never inside a stream capture)
+ */
+#ifndef MDD_HIP_H
+#define MDD_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mdd_model mdd_model;
+
+enum mdd_status {
+    MDD_OK = 0,
+    MDD_ERR_ARG = -1,       /* bad argument / shape */
+    MDD_ERR_HIP = -2,       /* a HIP runtime call failed */
+    MDD_ERR_STATE = -3,     /* weights missing / not finalised */
+    MDD_ERR_NOMEM = -4,
+    MDD_ERR_EMPTY = -5      /* mdd_align with an empty side: the reference raises TypeError */
+};
+
+/* per-utterance status written by mdd_beam: the exception the reference's BeamDecoder.decode
+ * would raise for that utterance (AA/utils/BeamSearch.py:64,66,103,106,135; AA/utils/NgramLM.py:75-76) */
+enum mdd_beam_status { MDD_BEAM_OK = 0, MDD_BEAM_INDEX_ERROR = 1, MDD_BEAM_VALUE_ERROR = 2, MDD_BEAM_KEY_ERROR = 3 };
+
+/* Geometry of CTC_Model.__init__ (AA/models/model_ctc.py:84-158) for the one architecture the
+ * reference recipe builds: 2x LayerCNN(k3x3, strides (1,2),(2,2), pad 1) -> `layers` x BiLSTM(hidden)
+ * -> Embedding(emb_rows, emb_dim) + BiLSTM text encoder -> dot attention -> BN + Linear(num_class). */
+typedef struct mdd_config {
+    int32_t feat;       /* stacked input width F (243 = 3 x 81), rnn_param["rnn_input_size"] */
+    int32_t hidden;     /* rnn_hidden_size H (384; 256 for BASELINE.json's variant); multiple of 16 */
+    int32_t layers;     /* rnn_layers (4) */
+    int32_t num_class;  /* C (45 for the 41-phone set) */
+    int32_t channels;   /* CNN channels (32) */
+    int32_t emb_rows;   /* 44  (model_ctc.py:149) */
+    int32_t emb_dim;    /* 512 (model_ctc.py:149-150); multiple of 4 */
+    float bn_eps;       /* 1e-5 */
+} mdd_config;
+
+const char *mdd_last_error(void);
+int mdd_version(void);
+
+/* ---- model lifetime + weights: replaces CTC_Model(...) + load_state_dict (AA/infer.py:251-254) */
+int mdd_create(const mdd_config *cfg, int device, mdd_model **out);
+void mdd_destroy(mdd_model *m);
+/* Copy one state_dict entry (host fp32, contiguous, reference key name and shape) to the device.
+ * `num_batches_tracked` entries are accepted and ignored. */
+int mdd_load_weight(mdd_model *m, const char *key, const float *data, const int64_t *shape, int32_t ndim);
+/* Check that all 55 float entries arrived, fold eval-mode BatchNorm into scale/shift vectors and
+ * repack LSTM gate rows for the step kernel.  Synchronises the device. */
+int mdd_finalize_weights(mdd_model *m);
+
+/* ---- A1: make_context(feat,0,right) + skip_feat(.,skip) + pad to a multiple of n_down
+ * (AA/utils/tools.py:207-227, AA/utils/data_loader.py:138-142) for B equal-length utterances.
+ * raw_dev [B,T_raw,D] -> out_dev [B,T_out,(right+1)*D] with T_out = mdd_stack_len(T_raw,skip,n_down). */
+int32_t mdd_stack_len(int32_t T_raw, int32_t skip, int32_t n_down);
+int mdd_stack_skip(const float *raw_dev, int32_t B, int32_t T_raw, int32_t D, int32_t right, int32_t skip,
+                   int32_t n_down, float *out_dev, void *stream);
+/* float32 length bookkeeping of create_input / infer (data_loader.py:177, infer.py:296-297) -- host */
+int32_t mdd_len_frames(int32_t len, int32_t maxlen, int32_t t_out);
+
+/* ---- A2-A7: CTC_Model.forward(x, x1) in eval mode (AA/models/model_ctc.py:160-223)
+ * x_dev [B,T,F] fp32 (T even), x1_dev [B,L] int64 canonical ids (0-padded) ->
+ * logp_dev [T/2,B,C] fp32 log-probabilities.  ids outside [0,emb_rows) are an error
+ * (the reference raises IndexError) and are reported by the next mdd_sync(). */
+int mdd_forward(mdd_model *m, const float *x_dev, int32_t B, int32_t T, const int64_t *x1_dev, int32_t L,
+                float *logp_dev, void *stream);
+/* Optional taps for parity tests: copies of stage outputs of the last mdd_forward (device buffers,
+ * valid until the next forward).  name: "conv1" [T/2,B,ch*W2], "rnn<i>" [T/2,B,2H] (raw, before the
+ * next layer's BatchNorm), "text" [L,B,2H], "key" [L,B,2H].  Returns the device pointer or NULL. */
+const float *mdd_tap(mdd_model *m, const char *name, int64_t *numel);
+/* Same, copied device-to-device into a caller buffer of `capacity` floats on `stream`. */
+int mdd_tap_copy(mdd_model *m, const char *name, float *dst_dev, int64_t capacity, void *stream);
+/* Keep the raw output of every BiLSTM layer (off by default: only the last layer's is needed). */
+int mdd_enable_taps(mdd_model *m, int32_t on);
+/* Wait for `stream` and report asynchronous errors of earlier calls on this handle. */
+int mdd_sync(mdd_model *m, void *stream);
+
+/* ---- A8: GreedyDecoder.decode (AA/utils/ctcDecoder.py:188-200, 80-92)
+ * logp_dev [T,B,C], len_dev [B] -> ids_dev [B,T] (collapsed, blanks removed), nids_dev [B]. */
+int mdd_greedy(const float *logp_dev, int32_t T, int32_t B, int32_t C, const int32_t *len_dev, int32_t blank,
+               int32_t *ids_dev, int32_t *nids_dev, void *stream);
+
+/* ---- A9: BeamDecoder.decode -> ctcBeamSearch.decode (AA/utils/ctcDecoder.py:215-226,
+ * AA/utils/BeamSearch.py:73-153): CTC prefix beam search, float64 scores.
+ * lm_dev: dense (C+1)x(C+1) table of natural-log bigram scores T[prev][next] as
+ * LanguageModel.get_bi_prob returns them (prev == C: sentence start, next == C: sentence end),
+ * NaN where the reference would raise KeyError.  beam <= 64, C <= 256.
+ * Outputs: ids_dev [B,T], nids_dev [B], status_dev [B] (mdd_beam_status), score_dev [B] or NULL
+ * (length-normalised score of the winner). */
+int mdd_beam(const float *logp_dev, int32_t T, int32_t B, int32_t C, const int32_t *len_dev, int32_t beam,
+             int32_t blank, const double *lm_dev, double lm_alpha, int32_t *ids_dev, int32_t *nids_dev,
+             int32_t *status_dev, double *score_dev, void *stream);
+
+/* ---- A12: nn.CTCLoss(reduction='sum') pieces (AA/steps/train_ctc.py:72,186): alpha/beta lattice.
+ * logp_dev [T,B,C], targets_dev [B,Lmax] int64 (padded), in_len_dev/tgt_len_dev [B] int64 ->
+ * nll_dev [B] (per-utterance negative log-likelihood; the reference's loss is their sum) and, if
+ * grad_dev != NULL, the tensor autograd deposits on the log-probs: [T,B,C]. */
+int mdd_ctc_loss(const float *logp_dev, int32_t T, int32_t B, int32_t C, const int64_t *targets_dev, int32_t Lmax,
+                 const int64_t *in_len_dev, const int64_t *tgt_len_dev, int32_t blank, float *nll_dev,
+                 float *grad_dev, void *stream);
+
+/* ---- A10: Decoder.wer core = _edit_distance + printChanges (AA/utils/ctcDecoder.py:118-184), host.
+ * a = hypothesis tokens, b = canonical tokens; ops (capacity >= na+nb): 0 '-', 1 'S', 2 'I', 3 'D'.
+ * Either side empty -> MDD_ERR_EMPTY (reference: TypeError). */
+int mdd_align(const int32_t *a, int32_t na, const int32_t *b, int32_t nb, int32_t *dist, uint8_t *ops,
+              int32_t *nops);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MDD_HIP_H */

@@ -1,0 +1,206 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle and the committed goldens.
+Tolerances: log-probs within 1e-4 absolute (BASELINE.json north_star); decoded ids / alignments exact."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle
+from tests.helpers import npz, jload, ids_to_beam_string, ids_to_greedy_string, GOLD
+from ctc_attention_mispronunciation_amd import synth
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def _hip():
+    from ctc_attention_mispronunciation_amd import hip_model
+    return hip_model
+
+
+def _cuda(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def test_forward_tiny_every_stage():
+    g = npz("g1_tiny.npz")
+    geom = synth.Geometry(**synth.TINY)
+    sd = synth.synth_state_dict(geom, seed=11)
+    m = _hip().HipModel(geom, sd, taps=True)
+    logp = m.forward(_cuda(g["x"]), _cuda(g["x1"]), sync_errors=True).cpu().numpy()
+    B, T = g["x"].shape[:2]
+    L = g["x1"].shape[1]
+    conv1 = m.tap("conv1").cpu().numpy().reshape(T // 2, B, geom.channels, -1).transpose(1, 2, 0, 3)
+    np.testing.assert_allclose(conv1, g["conv1"], rtol=0, atol=TOL)
+    for i in range(geom.layers):
+        np.testing.assert_allclose(m.tap("rnn%d" % i).cpu().numpy().reshape(T // 2, B, -1), g["rnn%d" % i], rtol=0, atol=TOL)
+    np.testing.assert_allclose(m.tap("text").cpu().numpy().reshape(L, B, -1).transpose(1, 0, 2), g["text"], rtol=0, atol=TOL)
+    np.testing.assert_allclose(m.tap("key").cpu().numpy().reshape(L, B, -1).transpose(1, 0, 2), g["key"], rtol=0, atol=TOL)
+    np.testing.assert_allclose(logp, g["logp"], rtol=0, atol=TOL)
+    np.testing.assert_allclose(logp, oracle.forward(sd, g["x"], g["x1"]), rtol=0, atol=TOL)
+
+
+@pytest.mark.parametrize("idx", [0, 1, 2])
+def test_forward_reference_geometry_golden(idx):
+    meta = jload("g2_ref.json")[idx]
+    ref = npz("g2_ref.npz")[meta["tag"] + "_logp"]
+    geom = synth.Geometry(**meta["geom"])
+    sd = synth.synth_state_dict(geom, seed=meta["seed"])
+    x, x1, _, _ = synth.synth_batch(geom, B=meta["B"], T=meta["T"], L=meta["L"], seed=meta["seed"])
+    m = _hip().HipModel(geom, sd)
+    logp = m.forward(_cuda(x), _cuda(x1)).cpu().numpy()
+    np.testing.assert_allclose(logp, ref, rtol=0, atol=TOL)
+    if meta["min_top2_gap"] > 1e-3:
+        assert (logp.argmax(-1) == ref.argmax(-1)).all()
+    # graph replay gives the same bits
+    again = m.forward(_cuda(x), _cuda(x1)).cpu().numpy()
+    np.testing.assert_array_equal(logp, again)
+
+
+def test_dropin_class_matches_golden_and_reference_api():
+    """The reference-shaped class: same constructor, state_dict keys, forward signature."""
+    import torch.nn as nn
+    from ctc_attention_mispronunciation_amd.models.model_ctc import CTC_Model
+    meta = jload("g2_ref.json")[0]
+    ref = npz("g2_ref.npz")[meta["tag"] + "_logp"]
+    geom = synth.Geometry(**meta["geom"])
+    sd = synth.synth_state_dict(geom, seed=meta["seed"])
+    model = CTC_Model(add_cnn=True, cnn_param=geom.cnn_param(nn), rnn_param=geom.rnn_param(nn), num_class=geom.num_class, drop_out=0.2)
+    assert set(model.state_dict().keys()) == set(sd.keys())
+    model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
+    model.eval()
+    x, x1, _, _ = synth.synth_batch(geom, B=meta["B"], T=meta["T"], L=meta["L"], seed=meta["seed"])
+    with torch.no_grad():
+        out_cpu_in = model(torch.from_numpy(x), torch.from_numpy(x1))          # CPU tensors in -> CPU tensor out
+        out_gpu_in = model(torch.from_numpy(x).cuda(), torch.from_numpy(x1).cuda())
+    assert not out_cpu_in.is_cuda and out_gpu_in.is_cuda
+    np.testing.assert_allclose(out_cpu_in.numpy(), ref, rtol=0, atol=TOL)
+    np.testing.assert_array_equal(out_cpu_in.numpy(), out_gpu_in.cpu().numpy())
+    bad = torch.from_numpy(x1).clone()
+    bad[0, 0] = 44                                                               # 'err' cannot be embedded (model_ctc.py:149)
+    with pytest.raises(IndexError):
+        model(torch.from_numpy(x), bad)
+    model.train()
+    with pytest.raises(NotImplementedError):
+        model(torch.from_numpy(x), torch.from_numpy(x1))
+
+
+def test_forward_full_size_properties():
+    """BASELINE config size (B=64, 10 s): rows are distributions; an utterance's posteriors do not depend on
+    the other utterances of the batch (eval mode has no cross-batch op), bit for bit; and a 2-utterance
+    slice agrees with the CPU oracle."""
+    geom = synth.Geometry(**synth.REFERENCE)
+    sd = synth.synth_state_dict(geom, seed=1234)
+    x, x1, _, _ = synth.synth_batch(geom, B=64, T=500, L=40, seed=1234, ragged=True)
+    m = _hip().HipModel(geom, sd)
+    logp = m.forward(_cuda(x), _cuda(x1))
+    assert logp.shape == (250, 64, 45)
+    s = torch.exp(logp.double()).sum(-1)
+    assert float((s - 1).abs().max()) < 1e-5
+    sub = [3, 40]
+    lp2 = m.forward(_cuda(x[sub]), _cuda(x1[sub]))
+    np.testing.assert_array_equal(lp2.cpu().numpy(), logp[:, sub, :].cpu().numpy())
+    ref = oracle.forward(sd, x[sub][:, :120], x1[sub])      # bounded slice for the scalar oracle (T=120)
+    lp3 = m.forward(_cuda(np.ascontiguousarray(x[sub][:, :120])), _cuda(x1[sub])).cpu().numpy()
+    np.testing.assert_allclose(lp3, ref, rtol=0, atol=TOL)
+
+
+@pytest.mark.parametrize("si", [0, 1])
+def test_decoders_golden(si, tmp_path):
+    from ctc_attention_mispronunciation_amd.utils.ctcDecoder import GreedyDecoder, BeamDecoder
+    meta = jload("g3_decode.json")["sets"][si]
+    g = npz("g3_decode.npz")
+    Cn = meta["C"]
+    i2c = dict(enumerate(meta["int2char"]))
+    greedy = GreedyDecoder(i2c, space_idx=-1, blank_index=0)
+    beams = {}
+    for r in meta["records"]:
+        lp = torch.from_numpy(g["c%d_case%d" % (Cn, r["case"])]).unsqueeze(1)
+        assert greedy.decode(lp, [r["len"]])[0] == r["greedy"], r
+        key = (r["alpha"], r["width"])
+        if key not in beams:
+            beams[key] = BeamDecoder(i2c, beam_width=r["width"], blank_index=0, space_idx=-1,
+                                     lm_path=os.path.join(GOLD, "lm_synth%d.arpa" % Cn), lm_alpha=r["alpha"])
+            np.testing.assert_array_equal(beams[key].lm.dense_table(i2c, Cn), g["lm%d" % Cn])
+        assert r["error"] is None
+        assert beams[key].decode(lp.cuda(), [r["len"]])[0] == r["beam"], r
+    for f in meta["failures"]:
+        lp = torch.from_numpy(g["c%d_fail_%s" % (Cn, f["name"])]).unsqueeze(1)
+        bd = BeamDecoder(i2c, beam_width=f["width"], blank_index=0, space_idx=-1,
+                         lm_path=os.path.join(GOLD, f["lm"].replace("lm", "lm_synth") + ".arpa"), lm_alpha=f["alpha"])
+        with pytest.raises({"IndexError": IndexError, "ValueError": ValueError, "KeyError": KeyError}[f["error"]]):
+            bd.decode(lp, [f["len"]])
+        assert greedy.decode(lp, [f["len"]])[0] == f["greedy"]
+    b = meta["batch"]
+    batch = torch.from_numpy(g["c%d_batch" % Cn])
+    assert greedy.decode(batch, b["lens"]) == b["greedy"]
+    assert beams[(0.0, 10)].decode(batch.cuda(), b["lens"]) == b["beam"]
+
+
+def test_decoders_full_size_against_oracle():
+    """B=64 x 250 frames: model-like flat posteriors and the 'peaky' set of SURVEY.md §8(d); ids must equal
+    the oracle's exactly, scores to 1e-9 relative."""
+    from ctc_attention_mispronunciation_amd.utils.ctcDecoder import GreedyDecoder, BeamDecoder
+    Cn, T, B = 45, 250, 64
+    i2c = synth.phone_table_41()
+    rs = np.random.Generator(np.random.PCG64(7))
+    lens = [T] + [int(v) for v in rs.integers(T // 2, T + 1, size=B - 1)]
+    bd = BeamDecoder(i2c, beam_width=10, blank_index=0, space_idx=-1, lm_path=os.path.join(GOLD, "lm_synth45.arpa"), lm_alpha=0.0)
+    table = bd.lm.dense_table(i2c, Cn)
+    for kind in ("peaky", "flat"):
+        if kind == "peaky":
+            lp = np.stack([synth.peaky_logp(T, Cn, 35, seed=100 + b) for b in range(B)], axis=1)
+        else:
+            z = rs.standard_normal((T, B, Cn)).astype(np.float32)
+            lp = torch.log_softmax(torch.from_numpy(z), -1).numpy()
+        ids, nids = GreedyDecoder(i2c, space_idx=-1, blank_index=0).decode_ids(torch.from_numpy(lp).cuda(), lens)
+        ids, nids = ids.cpu().numpy(), nids.cpu().numpy()
+        assert [ids[b, :nids[b]].tolist() for b in range(B)] == oracle.greedy(lp, lens)
+        ids, nids, st, sc = bd.decode_ids(torch.from_numpy(lp).cuda(), lens)
+        want, wst, wsc = oracle.beam(lp, lens, table, return_scores=True)
+        assert not st.cpu().numpy().any() and not wst.any()
+        ids, nids = ids.cpu().numpy(), nids.cpu().numpy()
+        assert [ids[b, :nids[b]].tolist() for b in range(B)] == want, kind
+        np.testing.assert_allclose(sc.cpu().numpy(), wsc, rtol=1e-9)
+
+
+def test_ctc_loss_golden_and_oracle():
+    g = npz("g5_ctc.npz")
+    for meta in jload("g5_ctc.json"):
+        i = meta["i"]
+        nll, grad = _hip().ctc_loss(_cuda(g["logp%d" % i]), _cuda(g["tg%d" % i]), _cuda(g["il%d" % i]), _cuda(g["tl%d" % i]))
+        nll, grad = nll.cpu().numpy(), grad.cpu().numpy()
+        ref_nll, ref_grad = g["nll%d" % i], g["grad%d" % i]
+        fin = np.isfinite(ref_nll)
+        assert (np.isinf(nll) == ~fin).all()
+        np.testing.assert_allclose(nll[fin], ref_nll[fin], rtol=2e-6, atol=1e-4)
+        np.testing.assert_allclose(grad[:, fin, :], ref_grad[:, fin, :], rtol=0, atol=TOL)
+        onll, ograd = oracle.ctc_loss(g["logp%d" % i], g["tg%d" % i], g["il%d" % i], g["tl%d" % i])
+        np.testing.assert_allclose(grad[:, fin, :], ograd[:, fin, :], rtol=0, atol=2e-6)
+    # BASELINE config (5) shard size: B=32, T'=250, L=40
+    rs = np.random.Generator(np.random.PCG64(12))
+    T, B, Cn, L = 250, 32, 45, 40
+    lp = torch.log_softmax(torch.from_numpy(rs.standard_normal((T, B, Cn)).astype(np.float32)), -1).numpy()
+    tg = rs.integers(1, Cn, size=(B, L))
+    il = rs.integers(2 * L + 1, T + 1, size=B); il[0] = T
+    tl = rs.integers(L // 2, L + 1, size=B); tl[0] = L
+    nll, grad = _hip().ctc_loss(_cuda(lp), _cuda(tg), _cuda(il), _cuda(tl))
+    onll, ograd = oracle.ctc_loss(lp, tg, il, tl)
+    np.testing.assert_allclose(nll.cpu().numpy(), onll, rtol=1e-6)
+    np.testing.assert_allclose(grad.cpu().numpy(), ograd, rtol=0, atol=2e-6)
+    # linearity property: sum over classes of the deposited gradient is 0 on every live frame
+    assert float(grad.sum(-1).abs().max()) < 1e-4
+
+
+def test_stack_skip_golden():
+    from ctc_attention_mispronunciation_amd.utils.data_loader import stack_features
+    g = npz("g6_input.npz")
+    for i in range(6):
+        np.testing.assert_array_equal(stack_features(torch.from_numpy(g["raw%d" % i])).cpu().numpy(), g["stk%d" % i])
+    raw = synth.synth_raw_features(4, T_raw=1000)
+    out = stack_features(torch.from_numpy(raw)).cpu().numpy()
+    assert out.shape == (4, 500, 243)
+    for b in range(4):
+        np.testing.assert_array_equal(out[b], oracle.stack_skip(raw[b]))
