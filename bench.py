@@ -1,0 +1,219 @@
+#!/usr/bin/env python3
+"""Contract bench: phoneme-frames/s of the joint CTC-attention decode hot path on MI355X.
+
+One "step" = one pass of the hot path over one reference-sized batch of synthetic utterances that is
+already resident in HBM: stack/skip (A1) -> CTC_Model.forward (A2-A7) -> CTC prefix beam search, width 10
+(A9) -> decoded ids back on the host -> edit-distance alignment against the canonical phonemes (A10).
+Workload (BASELINE.json configs[2], the configuration the metric is quoted on): B=64 utterances of 10 s
+(1000 x 81 log-mel+energy frames -> 250 posterior frames each), 4xBiLSTM-384, 41-phone set (45 classes),
+canonical length 40, beam 10, lm_alpha 0.  `--workload greedy32` runs configs[1] (B=32, greedy decode).
+
+N>1 (launched by torch.distributed.run, one rank per GPU): utterance batches shard across ranks (weak
+scaling: every rank decodes its own 64-utterance batch) and the posteriors of all shards are all-gathered
+over RCCL/xGMI each step, as BASELINE.json's north_star describes.
+
+Prints ONE JSON line on rank 0 (see the driver contract in the task statement) including `roofline`
+for the dominant kernel and a `cpu_baseline` measured in the same run on the host cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+PEAK_F32_MATRIX_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_* dense peak
+PEAK_HBM_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="joint64", choices=["joint64", "greedy32"])
+    ap.add_argument("--hidden", type=int, default=384)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-gather", action="store_true", help="skip the posterior all-gather at N>1")
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    from ctc_attention_mispronunciation_amd import synth, _lib
+    from ctc_attention_mispronunciation_amd.hip_model import HipModel
+    from ctc_attention_mispronunciation_amd.utils.ctcDecoder import GreedyDecoder, BeamDecoder, align_ids
+    from ctc_attention_mispronunciation_amd.utils.data_loader import stack_features
+
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    _lib.require_gpu()
+    torch.cuda.set_device(local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+
+    joint = args.workload == "joint64"
+    B = 64 if joint else 32
+    T_raw, D, L, beam_w = 1000, 81, 40, 10
+    geom = synth.Geometry(feat=243, hidden=args.hidden, layers=4, num_class=45)
+    sd = synth.synth_state_dict(geom, seed=1234)
+    # every rank decodes a different shard (different seed), same shapes
+    raw = torch.from_numpy(synth.synth_raw_features(B, T_raw, D, seed=1234 + rank)).cuda()
+    _, x1_np, _, _ = synth.synth_batch(geom, B=B, T=T_raw // 2, L=L, seed=1234 + rank, ragged=False)
+    x1 = torch.from_numpy(x1_np).cuda()
+    model = HipModel(geom, sd, device=local)
+    i2c = synth.phone_table_41()
+    arpa = os.path.join(ROOT, "tests", "golden", "lm_synth45.arpa")
+    decoder = (BeamDecoder(i2c, beam_width=beam_w, blank_index=0, space_idx=-1, lm_path=arpa, lm_alpha=0.0)
+               if joint else GreedyDecoder(i2c, space_idx=-1, blank_index=0))
+    Tp = T_raw // 4
+    lens = torch.full((B,), Tp, dtype=torch.int32, device="cuda")
+    canon = [x1_np[b].astype(np.int32) for b in range(B)]
+
+    # two-deep software pipeline: the forward of step i+1 runs on `s_fwd` while the (latency-bound,
+    # 64-workgroup) beam search of step i runs on `s_dec`; the host aligns step i-1 meanwhile.
+    s_fwd, s_dec = torch.cuda.Stream(), torch.cuda.Stream()
+    xbuf = torch.empty((B, T_raw // 2, 3 * D), device="cuda")   # fixed buffers: the forward graph is keyed on pointers
+    logp = [torch.empty((Tp, B, geom.num_class), device="cuda") for _ in range(2)]
+    gathered = [torch.empty((world, Tp, B, geom.num_class), device="cuda") for _ in range(2)] if world > 1 else None
+    h_ids = [torch.empty((B, Tp), dtype=torch.int32).pin_memory() for _ in range(2)]
+    h_n = [torch.empty((B,), dtype=torch.int32).pin_memory() for _ in range(2)]
+    ev_fwd = [torch.cuda.Event() for _ in range(2)]
+    ev_dec = [torch.cuda.Event() for _ in range(2)]
+    ev_free = [torch.cuda.Event() for _ in range(2)]
+    aligned = []
+
+    def enqueue(i):
+        k = i & 1
+        with torch.cuda.stream(s_fwd):
+            s_fwd.wait_event(ev_free[k])              # logp[k] no longer read by the decoder of step i-2
+            x = stack_features(raw, out=xbuf)
+            model.forward(x, x1, out=logp[k])
+            if gathered is not None and not args.no_gather:
+                dist.all_gather_into_tensor(gathered[k], logp[k])
+            ev_fwd[k].record(s_fwd)
+        with torch.cuda.stream(s_dec):
+            s_dec.wait_event(ev_fwd[k])
+            out = decoder.decode_ids(logp[k], lens)
+            ids, nids = out[0], out[1]
+            h_ids[k].copy_(ids, non_blocking=True)
+            h_n[k].copy_(nids, non_blocking=True)
+            ev_free[k].record(s_dec)
+            ev_dec[k].record(s_dec)
+
+    def finish(i):
+        k = i & 1
+        ev_dec[k].synchronize()
+        ids, n = h_ids[k].numpy(), h_n[k].numpy()
+        tot = 0
+        for b in range(B):
+            if n[b] > 0:
+                tot += align_ids((ids[b, :n[b]], canon[b]))[0]
+        aligned.append(tot)
+
+    def run(nsteps):
+        for i in range(nsteps):
+            enqueue(i)
+            if i >= 1:
+                finish(i - 1)
+        finish(nsteps - 1)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    run(max(args.warmup, 1))
+    barrier()
+    t0 = time.perf_counter()
+    run(args.steps)
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    frames = world * B * Tp * args.steps
+    value = frames / dt
+
+    # ---- roofline of the dominant kernel, measured with HIP events on the launch stream (stage replay)
+    roof = None
+    stages = None
+    if rank == 0:
+        x = stack_features(raw)
+        torch.cuda.synchronize()
+        reps = [model.profile(x, x1) for _ in range(3)]
+        stages = [(reps[0][i][0], float(np.median([r[i][1] for r in reps])), reps[0][i][2], reps[0][i][3]) for i in range(len(reps[0]))]
+        groups = {}
+        for name, ms, launches, flops in stages:
+            kern = ("lstm_step_kernel" if name.startswith("lstm") else "gemm_nt_f32_kernel" if name.startswith("gemm") else name)
+            g = groups.setdefault(kern, [0.0, 0, 0.0])
+            g[0] += ms; g[1] += launches; g[2] += flops
+        mfma = {k: v for k, v in groups.items() if k in ("lstm_step_kernel", "gemm_nt_f32_kernel")}
+        kern = max(mfma, key=lambda k: mfma[k][0])
+        ms, launches, flops = mfma[kern]
+        achieved = flops / (ms * 1e-3) / 1e12
+        roof = {"kernel": kern, "bound": "mfma", "achieved": round(achieved, 3), "peak": PEAK_F32_MATRIX_TFLOPS,
+                "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MATRIX_TFLOPS, 4), "traffic": None,
+                "launches_per_step": launches, "avg_launch_us": round(ms * 1e3 / launches, 3),
+                "flops_per_launch": flops / launches,
+                "stage_ms": {n: round(m, 4) for n, m, _, _ in stages}}
+
+    # ---- CPU baseline: the torch-CPU + Python-beam port of the reference path on a bounded sample
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import ref_port
+        ncores = min(os.cpu_count() or 1, 16)
+        torch.set_num_threads(ncores)
+        sb = 8
+        xs = stack_features(raw[:sb]).cpu().numpy()
+        ref_port.forward(sd, xs[:1, :64], x1_np[:1])                       # warm-up
+        t1 = time.perf_counter()
+        lp_cpu = ref_port.forward(sd, xs, x1_np[:sb])
+        t_fwd = time.perf_counter() - t1
+        t1 = time.perf_counter()
+        if joint:
+            ref_port.beam(lp_cpu, [Tp] * sb, i2c, decoder.lm, beam_w, 0.0)
+        else:
+            ref_port.greedy(lp_cpu, [Tp] * sb, i2c)
+        t_dec = time.perf_counter() - t1
+        cpu = {"value": round(sb * Tp / (t_fwd + t_dec), 1), "unit": "phoneme-frames/s", "cores": ncores, "kind": "port",
+               "sample": "%d of the same synthetic 10 s utterances (one batch): torch-CPU forward %.2f s + %s %.2f s"
+                         % (sb, t_fwd, "pure-Python beam(10)" if joint else "greedy", t_dec)}
+
+    if rank == 0:
+        line = {
+            "metric": "phoneme-frames/sec joint CTC-attn decode, 41-phone vocab",
+            "value": round(value, 1), "unit": "phoneme-frames/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": ("joint CTC-attn decode: stack/skip + forward + beam(10) + align, B=64 x 10 s x 81-dim log-mel"
+                                    if joint else "CTC-only greedy decode: stack/skip + forward + greedy + align, B=32 x 10 s"),
+                       "batch_per_gpu": B, "global_batch": B * world, "t_raw": T_raw, "posterior_frames": Tp,
+                       "hidden": args.hidden, "layers": 4, "num_class": 45, "canonical_len": L,
+                       "beam": beam_w if joint else 0, "lm_alpha": 0.0,
+                       "parallelism": "utterance-batch shards x%d%s" % (world, ", all-gather posteriors" if world > 1 and not args.no_gather else ""),
+                       "posteriors": "random-weight model output (flat: every frame live, beam worst case)"},
+            "roofline": roof, "cpu_baseline": cpu,
+            "edit_distance_checksum": int(sum(aligned[-args.steps:])),
+        }
+        print(json.dumps(line))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

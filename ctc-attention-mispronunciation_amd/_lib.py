@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_HERE, "libmdd_hip.so")
 
 EXPORTS = (
     "mdd_last_error", "mdd_version", "mdd_create", "mdd_destroy", "mdd_load_weight", "mdd_finalize_weights",
-    "mdd_stack_len", "mdd_stack_skip", "mdd_len_frames", "mdd_forward", "mdd_tap", "mdd_tap_copy", "mdd_enable_taps", "mdd_sync",
+    "mdd_stack_len", "mdd_stack_skip", "mdd_len_frames", "mdd_forward", "mdd_forward_num_stages", "mdd_forward_profile", "mdd_tap", "mdd_tap_copy", "mdd_enable_taps", "mdd_sync",
     "mdd_greedy", "mdd_beam", "mdd_ctc_loss", "mdd_align",
 )
 
@@ -37,6 +37,9 @@ def lib():
     if not os.path.exists(LIB_PATH):
         raise MddError("libmdd_hip.so not found at %s -- build it with `python -c 'import __graft_entry__ as g; "
                        "g.build()'` or `make -C ctc-attention-mispronunciation_amd/csrc` (no CPU fallback exists)" % LIB_PATH)
+    # torch first: the process must end up with ONE HIP runtime (the one torch ships), otherwise torch streams
+    # and device pointers would belong to a different runtime than the one libmdd_hip.so binds to.
+    import torch  # noqa: F401
     L = C.CDLL(LIB_PATH)
     vp, i32, i64p, f32p = C.c_void_p, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_float)
     L.mdd_last_error.restype = C.c_char_p
@@ -51,6 +54,8 @@ def lib():
     L.mdd_len_frames.argtypes = [i32, i32, i32]
     L.mdd_len_frames.restype = i32
     L.mdd_forward.argtypes = [vp, vp, i32, i32, vp, i32, vp, vp]
+    L.mdd_forward_num_stages.argtypes = [vp]
+    L.mdd_forward_profile.argtypes = [vp, vp, i32, i32, vp, i32, vp, vp, C.c_char_p, i32, vp, vp, vp, i32]
     L.mdd_tap.argtypes = [vp, C.c_char_p, i64p]
     L.mdd_tap.restype = vp
     L.mdd_tap_copy.argtypes = [vp, C.c_char_p, vp, C.c_int64, vp]

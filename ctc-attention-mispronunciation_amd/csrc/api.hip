@@ -26,7 +26,6 @@ struct DevBuf {
 struct GraphKey {
     const void *x, *x1, *out;
     int B, T, L;
-    hipStream_t st;
     bool operator<(const GraphKey &o) const { return memcmp(this, &o, sizeof(GraphKey)) < 0; }
 };
 
@@ -48,6 +47,7 @@ struct mdd_model {
     mdd::DevBuf y0, seq0, gx, act[2], xraw, hbuf, cbuf, embo, text, key, S;
     std::vector<mdd::DevBuf> tap_rnn;
     int *err_flag = nullptr;
+    hipStream_t cap_stream = nullptr;  // graphs are captured here (the legacy default stream cannot capture)
     int lastB = 0, lastT = 0, lastL = 0;
     std::map<mdd::GraphKey, hipGraphExec_t> graphs;
     int W1() const { return (cfg.feat + 2 - 3) / 2 + 1; }
@@ -112,43 +112,77 @@ static bool pack_gate_rows(mdd_model *m, const std::string &base, const char *wh
     return true;
 }
 
-static int forward_enqueue(mdd_model *m, const float *x, int B, int T, const int64_t *x1, int L, float *logp, hipStream_t st) {
+// The forward as an ordered list of stages (one or more kernel launches each).  mdd_forward captures all
+// of them into one graph; mdd_forward_profile replays them one by one between HIP events.
+struct Stage { const char *name; int launches; double flops; };
+
+static int n_stages(const mdd_model *m) { return 2 + 2 * m->cfg.layers + 6; }
+
+static int run_stage(mdd_model *m, int si, const float *x, int B, int T, const int64_t *x1, int L, float *logp,
+                     hipStream_t st, Stage *info) {
     const mdd_config &c = m->cfg;
-    const int H = c.hidden, H2 = 2 * H, G2 = 8 * H, Tp = T / 2, Lp = L;
-    int rc;
-    if ((rc = launch_conv0(x, m->w_conv0, m->sc0, m->sh0, m->y0.p, B, T, c.feat, c.channels, st))) return rc;
-    if ((rc = launch_conv1(m->y0.p, m->w_conv1t, m->sc1, m->sh1, m->seq0.p, B, T, m->W1(), c.channels, st))) return rc;
-    const float *in = m->seq0.p;
-    int K = m->rnn_in();
-    for (int n = 0; n < c.layers; n++) {
-        if ((rc = launch_gemm_nt(in, m->wih[n], nullptr, m->gx.p, Tp * B, G2, K, K, K, G2, 1, 0, 0, 0, st))) return rc;
-        const bool lastl = (n == c.layers - 1);
+    const int H = c.hidden, H2 = 2 * H, G2 = 8 * H, Tp = T / 2, Lp = L, nl = c.layers;
+    static thread_local char namebuf[32];
+    Stage dummy; if (!info) info = &dummy;
+    info->launches = 1; info->flops = 0.0;
+    if (si == 0) { info->name = "conv0"; info->flops = 2.0 * 9 * c.channels * (double)B * T * m->W1();
+        return launch_conv0(x, m->w_conv0, m->sc0, m->sh0, m->y0.p, B, T, c.feat, c.channels, st); }
+    if (si == 1) { info->name = "conv1"; info->flops = 2.0 * 9 * c.channels * c.channels * (double)B * Tp * m->W2();
+        return launch_conv1(m->y0.p, m->w_conv1t, m->sc1, m->sh1, m->seq0.p, B, T, m->W1(), c.channels, st); }
+    si -= 2;
+    if (si < 2 * nl) {
+        const int n = si / 2;
+        const float *in = n == 0 ? m->seq0.p : m->act[(n - 1) & 1].p;
+        const int K = n == 0 ? m->rnn_in() : H2;
+        if (si % 2 == 0) {
+            snprintf(namebuf, sizeof(namebuf), "gemm_ih%d", n); info->name = namebuf;
+            info->flops = 2.0 * (double)Tp * B * G2 * K;
+            return launch_gemm_nt(in, m->wih[n], nullptr, m->gx.p, Tp * B, G2, K, K, K, G2, 1, 0, 0, 0, st);
+        }
+        snprintf(namebuf, sizeof(namebuf), "lstm%d", n); info->name = namebuf;
+        info->launches = Tp; info->flops = 2.0 * 2 * (double)B * H * 4 * H * Tp;
         LstmStepArgs a;
         a.gx = m->gx.p; a.whh = m->whh[n]; a.hbuf = m->hbuf.p; a.cbuf = m->cbuf.p;
         a.T = Tp; a.B = B; a.H = H;
-        if (lastl) { a.out = m->xraw.p; a.out_raw = m->xraw.p; a.oscale = nullptr; a.oshift = nullptr; }
+        if (n == nl - 1) { a.out = m->xraw.p; a.out_raw = m->xraw.p; a.oscale = nullptr; a.oshift = nullptr; }
         else {
             a.out = m->act[n & 1].p; a.out_raw = m->taps ? m->tap_rnn[n].p : nullptr;
             a.oscale = m->bn_scale[n + 1]; a.oshift = m->bn_shift[n + 1];
         }
-        if ((rc = launch_lstm_layer(a, st))) return rc;
-        in = m->act[n & 1].p;
-        K = H2;
+        return launch_lstm_layer(a, st);
     }
-    // text encoder (model_ctc.py:193,198) and keys (:201)
-    if ((rc = launch_embed(m->emb, c.emb_rows, c.emb_dim, x1, B, L, m->embo.p, m->err_flag, st))) return rc;
-    if ((rc = launch_gemm_nt(m->embo.p, m->t_wih, m->t_bias, m->gx.p, L * B, G2, c.emb_dim, c.emb_dim, c.emb_dim, G2, 1, 0, 0, 0, st))) return rc;
-    {
+    si -= 2 * nl;
+    switch (si) {
+    case 0:  // text encoder (model_ctc.py:193,198) and keys (:201)
+        info->name = "embed";
+        return launch_embed(m->emb, c.emb_rows, c.emb_dim, x1, B, L, m->embo.p, m->err_flag, st);
+    case 1:
+        info->name = "gemm_text"; info->flops = 2.0 * (double)L * B * G2 * c.emb_dim;
+        return launch_gemm_nt(m->embo.p, m->t_wih, m->t_bias, m->gx.p, L * B, G2, c.emb_dim, c.emb_dim, c.emb_dim, G2, 1, 0, 0, 0, st);
+    case 2: {
+        info->name = "lstm_text"; info->launches = L; info->flops = 2.0 * 2 * (double)B * H * 4 * H * L;
         LstmStepArgs a;
         a.gx = m->gx.p; a.whh = m->t_whh; a.hbuf = m->hbuf.p; a.cbuf = m->cbuf.p;
         a.out = m->text.p; a.out_raw = m->text.p; a.oscale = nullptr; a.oshift = nullptr;
         a.T = L; a.B = B; a.H = H;
-        if ((rc = launch_lstm_layer(a, st))) return rc;
+        return launch_lstm_layer(a, st);
     }
-    if ((rc = launch_gemm_nt(m->text.p, m->w_score, nullptr, m->key.p, L * B, H2, H2, H2, H2, H2, 1, 0, 0, 0, st))) return rc;
-    // scores S[b][t][l] = X[t,b,:] . key[l,b,:]   (:204)
-    if ((rc = launch_gemm_nt(m->xraw.p, m->key.p, nullptr, m->S.p, Tp, L, H2, B * H2, B * H2, Lp, B, H2, H2, (long)Tp * Lp, st))) return rc;
-    return launch_attn_tail(m->S.p, Lp, m->xraw.p, m->text.p, m->fscale, m->fshift, m->w_fc, logp, Tp, B, L, H2, c.num_class, st);
+    case 3:
+        info->name = "gemm_key"; info->flops = 2.0 * (double)L * B * H2 * H2;
+        return launch_gemm_nt(m->text.p, m->w_score, nullptr, m->key.p, L * B, H2, H2, H2, H2, H2, 1, 0, 0, 0, st);
+    case 4:  // scores S[b][t][l] = X[t,b,:] . key[l,b,:]   (:204)
+        info->name = "gemm_score"; info->flops = 2.0 * (double)B * Tp * L * H2;
+        return launch_gemm_nt(m->xraw.p, m->key.p, nullptr, m->S.p, Tp, L, H2, B * H2, B * H2, Lp, B, H2, H2, (long)Tp * Lp, st);
+    default:
+        info->name = "attn_tail"; info->flops = 2.0 * (double)B * Tp * ((double)L * H2 + 2.0 * H2 * c.num_class);
+        return launch_attn_tail(m->S.p, Lp, m->xraw.p, m->text.p, m->fscale, m->fshift, m->w_fc, logp, Tp, B, L, H2, c.num_class, st);
+    }
+}
+
+static int forward_enqueue(mdd_model *m, const float *x, int B, int T, const int64_t *x1, int L, float *logp, hipStream_t st) {
+    for (int si = 0; si < n_stages(m); si++)
+        if (int rc = run_stage(m, si, x, B, T, x1, L, logp, st, nullptr)) return rc;
+    return MDD_OK;
 }
 
 }  // namespace mdd
@@ -183,6 +217,7 @@ extern "C" int mdd_create(const mdd_config *cfg, int device, mdd_model **out) {
     if (int rc = init_kernel_attributes()) { delete m; return rc; }
     hipError_t e = hipMalloc((void **)&m->err_flag, sizeof(int));
     if (e == hipSuccess) e = hipMemset(m->err_flag, 0, sizeof(int));
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&m->cap_stream, hipStreamNonBlocking);
     if (e != hipSuccess) { set_error("mdd_create: %s", hipGetErrorString(e)); delete m; return MDD_ERR_HIP; }
     *out = m;
     return MDD_OK;
@@ -198,6 +233,7 @@ extern "C" void mdd_destroy(mdd_model *m) {
     for (DevBuf *b : bufs) if (b->p) (void)hipFree(b->p);
     for (auto &b : m->tap_rnn) if (b.p) (void)hipFree(b.p);
     if (m->err_flag) (void)hipFree(m->err_flag);
+    if (m->cap_stream) (void)hipStreamDestroy(m->cap_stream);
     delete m;
 }
 
@@ -308,16 +344,14 @@ extern "C" int32_t mdd_len_frames(int32_t len, int32_t maxlen, int32_t t_out) {
     return (int32_t)prod;
 }
 
-extern "C" int mdd_forward(mdd_model *m, const float *x_dev, int32_t B, int32_t T, const int64_t *x1_dev, int32_t L,
-                           float *logp_dev, void *stream) {
+static int forward_prepare(mdd_model *m, const float *x_dev, int32_t B, int32_t T, const int64_t *x1_dev, int32_t L, float *logp_dev) {
     if (!m || !x_dev || !x1_dev || !logp_dev) { set_error("mdd_forward: null pointer"); return MDD_ERR_ARG; }
     if (!m->finalized) { set_error("mdd_forward: call mdd_finalize_weights first"); return MDD_ERR_STATE; }
     if (B <= 0 || T < 2 || L <= 0) { set_error("mdd_forward: bad shape B=%d T=%d L=%d", B, T, L); return MDD_ERR_ARG; }
-    MDD_HIP_CHECK(hipSetDevice(m->device));
-    hipStream_t st = (hipStream_t)stream;
-    const mdd_config &c = m->cfg;
-    const int H = c.hidden, Tp = (T + 2 - 3) / 2 + 1;  // conv1 time stride 2, pad 1, k 3
     if (T % 2) { set_error("mdd_forward: T must be even (data_loader.py:140-142 pads to n_downsample)"); return MDD_ERR_ARG; }
+    MDD_HIP_CHECK(hipSetDevice(m->device));
+    const mdd_config &c = m->cfg;
+    const int H = c.hidden, Tp = T / 2;
     int rc;
     const size_t rows = (size_t)Tp * B, trows = (size_t)L * B, mrows = rows > trows ? rows : trows;
     if ((rc = ensure(m->y0, (size_t)B * c.channels * T * m->W1())) || (rc = ensure(m->seq0, rows * m->rnn_in())) ||
@@ -336,18 +370,25 @@ extern "C" int mdd_forward(mdd_model *m, const float *x_dev, int32_t B, int32_t 
         m->graphs.clear();
         g_ws_moved = false;
     }
-    if (!m->use_graph) return forward_enqueue(m, x_dev, B, T, x1_dev, L, logp_dev, st);
+    return MDD_OK;
+}
 
+extern "C" int mdd_forward(mdd_model *m, const float *x_dev, int32_t B, int32_t T, const int64_t *x1_dev, int32_t L,
+                           float *logp_dev, void *stream) {
+    int rc = forward_prepare(m, x_dev, B, T, x1_dev, L, logp_dev);
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    if (!m->use_graph) return forward_enqueue(m, x_dev, B, T, x1_dev, L, logp_dev, st);
     GraphKey key;
     memset(&key, 0, sizeof(key));
-    key.x = x_dev; key.x1 = x1_dev; key.out = logp_dev; key.B = B; key.T = T; key.L = L; key.st = st;
+    key.x = x_dev; key.x1 = x1_dev; key.out = logp_dev; key.B = B; key.T = T; key.L = L;
     auto it = m->graphs.find(key);
     if (it == m->graphs.end()) {
         if (m->graphs.size() >= 8) { for (auto &kv : m->graphs) (void)hipGraphExecDestroy(kv.second); m->graphs.clear(); }
         hipGraph_t graph = nullptr;
-        MDD_HIP_CHECK(hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed));
-        rc = forward_enqueue(m, x_dev, B, T, x1_dev, L, logp_dev, st);
-        hipError_t e = hipStreamEndCapture(st, &graph);
+        MDD_HIP_CHECK(hipStreamBeginCapture(m->cap_stream, hipStreamCaptureModeRelaxed));
+        rc = forward_enqueue(m, x_dev, B, T, x1_dev, L, logp_dev, m->cap_stream);
+        hipError_t e = hipStreamEndCapture(m->cap_stream, &graph);
         if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
         if (e != hipSuccess) { set_error("graph capture failed: %s", hipGetErrorString(e)); return MDD_ERR_HIP; }
         hipGraphExec_t exec = nullptr;
@@ -357,6 +398,49 @@ extern "C" int mdd_forward(mdd_model *m, const float *x_dev, int32_t B, int32_t 
         it = m->graphs.emplace(key, exec).first;
     }
     MDD_HIP_CHECK(hipGraphLaunch(it->second, st));
+    return MDD_OK;
+}
+
+extern "C" int32_t mdd_forward_num_stages(mdd_model *m) { return m ? n_stages(m) : 0; }
+
+extern "C" int mdd_forward_profile(mdd_model *m, const float *x_dev, int32_t B, int32_t T, const int64_t *x1_dev, int32_t L,
+                                   float *logp_dev, void *stream, char *names, int32_t names_cap, float *ms,
+                                   int32_t *launches, double *flops, int32_t cap) {
+    int rc = forward_prepare(m, x_dev, B, T, x1_dev, L, logp_dev);
+    if (rc) return rc;
+    const int ns = n_stages(m);
+    if (cap < ns || !ms || !launches || !flops || !names) { set_error("mdd_forward_profile: need room for %d stages", ns); return MDD_ERR_ARG; }
+    hipStream_t st = (hipStream_t)stream;
+    hipEvent_t e0, e1;
+    MDD_HIP_CHECK(hipEventCreate(&e0));
+    MDD_HIP_CHECK(hipEventCreate(&e1));
+    std::string all;
+    for (int si = 0; si < ns; si++) {
+        Stage info;
+        hipGraph_t graph = nullptr;
+        MDD_HIP_CHECK(hipStreamBeginCapture(m->cap_stream, hipStreamCaptureModeRelaxed));
+        rc = run_stage(m, si, x_dev, B, T, x1_dev, L, logp_dev, m->cap_stream, &info);
+        hipError_t e = hipStreamEndCapture(m->cap_stream, &graph);
+        if (rc || e != hipSuccess) { if (graph) (void)hipGraphDestroy(graph); if (!rc) set_error("stage capture failed"); return rc ? rc : MDD_ERR_HIP; }
+        hipGraphExec_t exec = nullptr;
+        e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(graph);
+        if (e != hipSuccess) { set_error("stage instantiate failed: %s", hipGetErrorString(e)); return MDD_ERR_HIP; }
+        MDD_HIP_CHECK(hipGraphLaunch(exec, st));          // warm (first replay pays upload)
+        MDD_HIP_CHECK(hipStreamSynchronize(st));
+        MDD_HIP_CHECK(hipEventRecord(e0, st));
+        MDD_HIP_CHECK(hipGraphLaunch(exec, st));
+        MDD_HIP_CHECK(hipEventRecord(e1, st));
+        MDD_HIP_CHECK(hipEventSynchronize(e1));
+        float t = 0.f;
+        MDD_HIP_CHECK(hipEventElapsedTime(&t, e0, e1));
+        (void)hipGraphExecDestroy(exec);
+        ms[si] = t; launches[si] = info.launches; flops[si] = info.flops;
+        if (si) all += ",";
+        all += info.name;
+    }
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    snprintf(names, names_cap, "%s", all.c_str());
     return MDD_OK;
 }
 

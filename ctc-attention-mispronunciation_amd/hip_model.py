@@ -48,6 +48,18 @@ class HipModel(object):
                 raise IndexError(_lib.lib().mdd_last_error().decode())
         return out
 
+    def profile(self, x, x1):
+        """Per-stage (name, ms, launches, flops) of one forward replayed stage by stage between HIP events."""
+        B, T, _ = x.shape
+        out = torch.empty((T // 2, B, self.geom.num_class), dtype=torch.float32, device=x.device)
+        n = _lib.lib().mdd_forward_num_stages(self.handle)
+        names = C.create_string_buffer(64 * n)
+        ms, launches, flops = (C.c_float * n)(), (C.c_int32 * n)(), (C.c_double * n)()
+        _lib.check(_lib.lib().mdd_forward_profile(self.handle, C.c_void_p(x.data_ptr()), B, T, C.c_void_p(x1.data_ptr()),
+                                                  x1.shape[1], C.c_void_p(out.data_ptr()), _lib.current_stream_ptr(),
+                                                  names, 64 * n, ms, launches, flops, n))
+        return list(zip(names.value.decode().split(","), list(ms), list(launches), list(flops)))
+
     def tap(self, name):
         n = C.c_int64(0)
         if not _lib.lib().mdd_tap(self.handle, name.encode(), C.byref(n)):

@@ -42,7 +42,7 @@ class Vocab(object):
         print("Vocabulary size is {}".format(self.n_words))
 
 
-def stack_features(raw, right_ctx=2, n_skip_frame=2, n_downsample=2):
+def stack_features(raw, right_ctx=2, n_skip_frame=2, n_downsample=2, out=None):
     """raw [B, T_raw, D] (or [T_raw, D]) float tensor -> stacked [B, T, (right_ctx+1)*D] on the GPU:
     make_context(feat, 0, right_ctx) + skip_feat(., n_skip_frame) + zero-pad to a multiple of n_downsample."""
     _lib.require_gpu()
@@ -50,10 +50,12 @@ def stack_features(raw, right_ctx=2, n_skip_frame=2, n_downsample=2):
     r = (raw.unsqueeze(0) if single else raw).to("cuda", torch.float32).contiguous()
     B, T_raw, D = r.shape
     T = _lib.lib().mdd_stack_len(T_raw, n_skip_frame, n_downsample)
-    out = torch.empty((B, T, (right_ctx + 1) * D), dtype=torch.float32, device=r.device)
+    if out is None:
+        out = torch.empty((B, T, (right_ctx + 1) * D), dtype=torch.float32, device=r.device)
+    assert out.is_contiguous() and out.numel() == B * T * (right_ctx + 1) * D
     _lib.check(_lib.lib().mdd_stack_skip(C.c_void_p(r.data_ptr()), B, T_raw, D, right_ctx, n_skip_frame, n_downsample,
                                          C.c_void_p(out.data_ptr()), _lib.current_stream_ptr()))
-    return out[0] if single else out
+    return out.view(T, -1) if single else out.view(B, T, -1)
 
 
 def frames_from_fraction(input_sizes, t_out):

@@ -82,6 +82,12 @@ int32_t mdd_len_frames(int32_t len, int32_t maxlen, int32_t t_out);
  * (the reference raises IndexError) and are reported by the next mdd_sync(). */
 int mdd_forward(mdd_model *m, const float *x_dev, int32_t B, int32_t T, const int64_t *x1_dev, int32_t L,
                 float *logp_dev, void *stream);
+/* The same forward replayed stage by stage between HIP events on `stream` (measurement aid for bench.py:
+ * per-stage wall time, kernel launches and algorithmic flops).  names: comma-separated stage names. */
+int32_t mdd_forward_num_stages(mdd_model *m);
+int mdd_forward_profile(mdd_model *m, const float *x_dev, int32_t B, int32_t T, const int64_t *x1_dev, int32_t L,
+                        float *logp_dev, void *stream, char *names, int32_t names_cap, float *ms, int32_t *launches,
+                        double *flops, int32_t cap);
 /* Optional taps for parity tests: copies of stage outputs of the last mdd_forward (device buffers,
  * valid until the next forward).  name: "conv1" [T/2,B,ch*W2], "rnn<i>" [T/2,B,2H] (raw, before the
  * next layer's BatchNorm), "text" [L,B,2H], "key" [L,B,2H].  Returns the device pointer or NULL. */

@@ -16,7 +16,7 @@ def test_library_exports_every_declared_symbol():
     header = open(os.path.join(ROOT, "include", "mdd_hip.h")).read()
     declared = set(re.findall(r"\b(mdd_[a-z_0-9]+)\s*\(", header))
     assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
-    lib = ctypes.CDLL(_lib.LIB_PATH)
+    lib = _lib.lib()
     for name in declared:
         assert hasattr(lib, name), name
     assert _lib.lib().mdd_version() == 100

@@ -102,3 +102,33 @@ def test_g6_stack_skip_and_lengths():
     assert i == 6
     for ln, maxlen, tout, want in g["len_table"]:
         assert oracle.len_frames(ln, maxlen, tout) == want, (ln, maxlen, tout)
+
+
+# ---------------------------------------------------------------------------- the torch/Python port (CPU baseline)
+def test_ref_port_forward_matches_goldens():
+    from oracle import ref_port
+    g = npz("g2_ref.npz")
+    for meta in jload("g2_ref.json"):
+        geom = synth.Geometry(**meta["geom"])
+        sd = synth.synth_state_dict(geom, seed=meta["seed"])
+        x, x1, _, _ = synth.synth_batch(geom, B=meta["B"], T=meta["T"], L=meta["L"], seed=meta["seed"])
+        np.testing.assert_allclose(ref_port.forward(sd, x, x1).numpy(), g[meta["tag"] + "_logp"], rtol=0, atol=2e-6)
+
+
+def test_ref_port_decoders_match_goldens():
+    import os
+    from oracle import ref_port
+    from ctc_attention_mispronunciation_amd.utils.NgramLM import LanguageModel
+    from tests.helpers import GOLD
+    meta = jload("g3_decode.json")["sets"][1]          # the 9-class set keeps the pure-Python beam quick
+    g = npz("g3_decode.npz")
+    Cn, i2c = meta["C"], dict(enumerate(meta["int2char"]))
+    lm = LanguageModel(os.path.join(GOLD, "lm_synth%d.arpa" % Cn))
+    for r in meta["records"]:
+        lp = g["c%d_case%d" % (Cn, r["case"])][:, None, :]
+        assert ref_port.greedy(lp, [r["len"]], i2c)[0] == r["greedy"]
+        assert ref_port.beam(lp, [r["len"]], i2c, lm, r["width"], r["alpha"])[0] == r["beam"], r
+    for f in meta["failures"]:
+        lmf = LanguageModel(os.path.join(GOLD, f["lm"].replace("lm", "lm_synth") + ".arpa"))
+        with pytest.raises({"IndexError": IndexError, "ValueError": ValueError, "KeyError": KeyError}[f["error"]]):
+            ref_port.beam(g["c%d_fail_%s" % (Cn, f["name"])][:, None, :], [f["len"]], i2c, lmf, f["width"], f["alpha"])
