@@ -38,6 +38,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="joint64", choices=["joint64", "greedy32"])
     ap.add_argument("--hidden", type=int, default=384)
+    ap.add_argument("--lanes", type=int, default=1, help="independent stream pipelines per GPU")
+    ap.add_argument("--fuse", type=int, default=4, help="reference-sized batches carried by one launch sequence")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true", help="skip the posterior all-gather at N>1")
     return ap.parse_args()
@@ -65,7 +67,10 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
 
     joint = args.workload == "joint64"
-    B = 64 if joint else 32
+    import math
+    G = math.gcd(max(1, args.fuse), args.steps)      # batches fused per pass; a step stays one 64-utterance batch
+    B0 = 64 if joint else 32
+    B = B0 * G
     T_raw, D, L, beam_w = 1000, 81, 40, 10
     geom = synth.Geometry(feat=243, hidden=args.hidden, layers=4, num_class=45)
     sd = synth.synth_state_dict(geom, seed=1234)
@@ -82,53 +87,67 @@ def main():
     lens = torch.full((B,), Tp, dtype=torch.int32, device="cuda")
     canon = [x1_np[b].astype(np.int32) for b in range(B)]
 
-    # two-deep software pipeline: the forward of step i+1 runs on `s_fwd` while the (latency-bound,
-    # 64-workgroup) beam search of step i runs on `s_dec`; the host aligns step i-1 meanwhile.
-    s_fwd, s_dec = torch.cuda.Stream(), torch.cuda.Stream()
-    xbuf = torch.empty((B, T_raw // 2, 3 * D), device="cuda")   # fixed buffers: the forward graph is keyed on pointers
-    logp = [torch.empty((Tp, B, geom.num_class), device="cuda") for _ in range(2)]
-    gathered = [torch.empty((world, Tp, B, geom.num_class), device="cuda") for _ in range(2)] if world > 1 else None
-    h_ids = [torch.empty((B, Tp), dtype=torch.int32).pin_memory() for _ in range(2)]
-    h_n = [torch.empty((B,), dtype=torch.int32).pin_memory() for _ in range(2)]
-    ev_fwd = [torch.cuda.Event() for _ in range(2)]
-    ev_dec = [torch.cuda.Event() for _ in range(2)]
-    ev_free = [torch.cuda.Event() for _ in range(2)]
+    # Software pipeline.  `lanes` independent batch pipelines are in flight at once (each with its own library
+    # handle = its own workspace and captured graphs): the BiLSTM recurrence is a chain of ~1000 dependent
+    # ~5 us launches per batch that leaves most CUs idle, so interleaving independent batches on separate
+    # HIP streams hides that latency.  Inside a lane the forward of its next batch (stream s_fwd) overlaps the
+    # latency-bound beam search of its previous one (s_dec); the host aligns finished batches meanwhile.
+    class Lane(object):
+        def __init__(self, mdl):
+            self.model = mdl
+            self.s_fwd, self.s_dec = torch.cuda.Stream(), torch.cuda.Stream()
+            self.xbuf = torch.empty((B, T_raw // 2, 3 * D), device="cuda")   # fixed buffers: graphs are keyed on pointers
+            self.logp = [torch.empty((Tp, B, geom.num_class), device="cuda") for _ in range(2)]
+            self.gathered = ([torch.empty((world, Tp, B, geom.num_class), device="cuda") for _ in range(2)]
+                             if world > 1 else None)
+            self.h_ids = [torch.empty((B, Tp), dtype=torch.int32).pin_memory() for _ in range(2)]
+            self.h_n = [torch.empty((B,), dtype=torch.int32).pin_memory() for _ in range(2)]
+            self.ev_fwd = [torch.cuda.Event() for _ in range(2)]
+            self.ev_dec = [torch.cuda.Event() for _ in range(2)]
+            self.ev_free = [torch.cuda.Event() for _ in range(2)]
+            self.count = 0
+
+        def enqueue(self):
+            k = self.count & 1
+            self.count += 1
+            with torch.cuda.stream(self.s_fwd):
+                self.s_fwd.wait_event(self.ev_free[k])          # logp[k] no longer read by the decoder two batches ago
+                x = stack_features(raw, out=self.xbuf)
+                self.model.forward(x, x1, out=self.logp[k])
+                if self.gathered is not None and not args.no_gather:
+                    dist.all_gather_into_tensor(self.gathered[k], self.logp[k])
+                self.ev_fwd[k].record(self.s_fwd)
+            with torch.cuda.stream(self.s_dec):
+                self.s_dec.wait_event(self.ev_fwd[k])
+                out = decoder.decode_ids(self.logp[k], lens)
+                self.h_ids[k].copy_(out[0], non_blocking=True)
+                self.h_n[k].copy_(out[1], non_blocking=True)
+                self.ev_free[k].record(self.s_dec)
+                self.ev_dec[k].record(self.s_dec)
+            return k
+
+        def finish(self, k):
+            self.ev_dec[k].synchronize()
+            ids, n = self.h_ids[k].numpy(), self.h_n[k].numpy()
+            tot = 0
+            for b in range(B):
+                if n[b] > 0:
+                    tot += align_ids((ids[b, :n[b]], canon[b]))[0]
+            aligned.append(tot)
+
     aligned = []
-
-    def enqueue(i):
-        k = i & 1
-        with torch.cuda.stream(s_fwd):
-            s_fwd.wait_event(ev_free[k])              # logp[k] no longer read by the decoder of step i-2
-            x = stack_features(raw, out=xbuf)
-            model.forward(x, x1, out=logp[k])
-            if gathered is not None and not args.no_gather:
-                dist.all_gather_into_tensor(gathered[k], logp[k])
-            ev_fwd[k].record(s_fwd)
-        with torch.cuda.stream(s_dec):
-            s_dec.wait_event(ev_fwd[k])
-            out = decoder.decode_ids(logp[k], lens)
-            ids, nids = out[0], out[1]
-            h_ids[k].copy_(ids, non_blocking=True)
-            h_n[k].copy_(nids, non_blocking=True)
-            ev_free[k].record(s_dec)
-            ev_dec[k].record(s_dec)
-
-    def finish(i):
-        k = i & 1
-        ev_dec[k].synchronize()
-        ids, n = h_ids[k].numpy(), h_n[k].numpy()
-        tot = 0
-        for b in range(B):
-            if n[b] > 0:
-                tot += align_ids((ids[b, :n[b]], canon[b]))[0]
-        aligned.append(tot)
+    lanes = [Lane(model)] + [Lane(HipModel(geom, sd, device=local)) for _ in range(args.lanes - 1)]
 
     def run(nsteps):
+        pending = []
         for i in range(nsteps):
-            enqueue(i)
-            if i >= 1:
-                finish(i - 1)
-        finish(nsteps - 1)
+            ln = lanes[i % len(lanes)]
+            pending.append((ln, ln.enqueue()))
+            if len(pending) > len(lanes):                    # keep at most one finished-but-unaligned batch per lane
+                l0, k0 = pending.pop(0)
+                l0.finish(k0)
+        for l0, k0 in pending:
+            l0.finish(k0)
 
     def barrier():
         torch.cuda.synchronize()
@@ -136,17 +155,18 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    run(max(args.warmup, 1))
+    run(max((args.warmup + G - 1) // G, 1))
     barrier()
     t0 = time.perf_counter()
-    run(args.steps)
+    run(args.steps // G)
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
         t = torch.tensor([dt], device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    frames = world * B * Tp * args.steps
+    npass = args.steps // G
+    frames = world * B * Tp * npass
     value = frames / dt
 
     # ---- roofline of the dominant kernel, measured with HIP events on the launch stream (stage replay)
@@ -168,7 +188,7 @@ def main():
         achieved = flops / (ms * 1e-3) / 1e12
         roof = {"kernel": kern, "bound": "mfma", "achieved": round(achieved, 3), "peak": PEAK_F32_MATRIX_TFLOPS,
                 "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MATRIX_TFLOPS, 4), "traffic": None,
-                "launches_per_step": launches, "avg_launch_us": round(ms * 1e3 / launches, 3),
+                "launches_per_pass": launches, "avg_launch_us": round(ms * 1e3 / launches, 3), "batches_per_pass": G,
                 "flops_per_launch": flops / launches,
                 "stage_ms": {n: round(m, 4) for n, m, _, _ in stages}}
 
@@ -202,13 +222,13 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": ("joint CTC-attn decode: stack/skip + forward + beam(10) + align, B=64 x 10 s x 81-dim log-mel"
                                     if joint else "CTC-only greedy decode: stack/skip + forward + greedy + align, B=32 x 10 s"),
-                       "batch_per_gpu": B, "global_batch": B * world, "t_raw": T_raw, "posterior_frames": Tp,
+                       "batch_per_gpu": B0, "global_batch": B0 * world, "batches_fused_per_pass": G, "t_raw": T_raw, "posterior_frames": Tp,
                        "hidden": args.hidden, "layers": 4, "num_class": 45, "canonical_len": L,
-                       "beam": beam_w if joint else 0, "lm_alpha": 0.0,
+                       "beam": beam_w if joint else 0, "lm_alpha": 0.0, "batches_in_flight": args.lanes,
                        "parallelism": "utterance-batch shards x%d%s" % (world, ", all-gather posteriors" if world > 1 and not args.no_gather else ""),
                        "posteriors": "random-weight model output (flat: every frame live, beam worst case)"},
             "roofline": roof, "cpu_baseline": cpu,
-            "edit_distance_checksum": int(sum(aligned[-args.steps:])),
+            "edit_distance_checksum": int(sum(aligned[-(args.steps // G):])),
         }
         print(json.dumps(line))
     if dist is not None:

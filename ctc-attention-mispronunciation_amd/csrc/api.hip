@@ -41,7 +41,7 @@ struct mdd_model {
     float *w_conv1t = nullptr, *sc1 = nullptr, *sh1 = nullptr;
     std::vector<float *> wih, whh, bn_scale, bn_shift;  // per rnn layer (bn_* of layer n applies to layer n's INPUT)
     float *emb = nullptr, *t_wih = nullptr, *t_whh = nullptr, *t_bias = nullptr;
-    float *w_score = nullptr, *fscale = nullptr, *fshift = nullptr, *w_fc = nullptr;
+    float *w_score = nullptr, *fscale = nullptr, *fshift = nullptr, *w_fc = nullptr, *w_fcp = nullptr;
     std::vector<void *> owned;  // every hipMalloc'd weight pointer
     // workspace
     mdd::DevBuf y0, seq0, gx, act[2], xraw, hbuf, cbuf, embo, text, key, S;
@@ -72,6 +72,7 @@ static int ensure(DevBuf &b, size_t n) {
     if (b.p) MDD_HIP_CHECK(hipFree(b.p));
     b.p = nullptr; b.cap = 0;
     MDD_HIP_CHECK(hipMalloc((void **)&b.p, n * sizeof(float)));
+    MDD_HIP_CHECK(hipMemset(b.p, 0, n * sizeof(float)));  // padded batch rows of the packed h exchange must be finite
     b.cap = n;
     return MDD_OK;
 }
@@ -112,6 +113,21 @@ static bool pack_gate_rows(mdd_model *m, const std::string &base, const char *wh
     return true;
 }
 
+static bool use_packed(const mdd_model *m) { return m->cfg.hidden == 384 || m->cfg.hidden == 256; }
+
+// Whh' [2][4H][H] (gate-permuted rows) -> Wp[d][ut][j][lane][m] (see lstm.hip)
+static void pack_whh(const std::vector<float> &w, int H, std::vector<float> &out) {
+    const int NUT = H / 4, J = H / 16;
+    out.resize(w.size());
+    for (int d = 0; d < 2; d++)
+        for (int ut = 0; ut < NUT; ut++)
+            for (int j = 0; j < J; j++)
+                for (int lane = 0; lane < 64; lane++)
+                    for (int mm = 0; mm < 4; mm++)
+                        out[((((size_t)d * NUT + ut) * J + j) * 64 + lane) * 4 + mm] =
+                            w[((size_t)d * 4 * H + ut * 16 + (lane & 15)) * H + 16 * j + 4 * (lane >> 4) + mm];
+}
+
 // The forward as an ordered list of stages (one or more kernel launches each).  mdd_forward captures all
 // of them into one graph; mdd_forward_profile replays them one by one between HIP events.
 struct Stage { const char *name; int launches; double flops; };
@@ -143,7 +159,7 @@ static int run_stage(mdd_model *m, int si, const float *x, int B, int T, const i
         info->launches = Tp; info->flops = 2.0 * 2 * (double)B * H * 4 * H * Tp;
         LstmStepArgs a;
         a.gx = m->gx.p; a.whh = m->whh[n]; a.hbuf = m->hbuf.p; a.cbuf = m->cbuf.p;
-        a.T = Tp; a.B = B; a.H = H;
+        a.T = Tp; a.B = B; a.H = H; a.packed = use_packed(m);
         if (n == nl - 1) { a.out = m->xraw.p; a.out_raw = m->xraw.p; a.oscale = nullptr; a.oshift = nullptr; }
         else {
             a.out = m->act[n & 1].p; a.out_raw = m->taps ? m->tap_rnn[n].p : nullptr;
@@ -164,7 +180,7 @@ static int run_stage(mdd_model *m, int si, const float *x, int B, int T, const i
         LstmStepArgs a;
         a.gx = m->gx.p; a.whh = m->t_whh; a.hbuf = m->hbuf.p; a.cbuf = m->cbuf.p;
         a.out = m->text.p; a.out_raw = m->text.p; a.oscale = nullptr; a.oshift = nullptr;
-        a.T = L; a.B = B; a.H = H;
+        a.T = L; a.B = B; a.H = H; a.packed = use_packed(m);
         return launch_lstm_layer(a, st);
     }
     case 3:
@@ -175,7 +191,7 @@ static int run_stage(mdd_model *m, int si, const float *x, int B, int T, const i
         return launch_gemm_nt(m->xraw.p, m->key.p, nullptr, m->S.p, Tp, L, H2, B * H2, B * H2, Lp, B, H2, H2, (long)Tp * Lp, st);
     default:
         info->name = "attn_tail"; info->flops = 2.0 * (double)B * Tp * ((double)L * H2 + 2.0 * H2 * c.num_class);
-        return launch_attn_tail(m->S.p, Lp, m->xraw.p, m->text.p, m->fscale, m->fshift, m->w_fc, logp, Tp, B, L, H2, c.num_class, st);
+        return launch_attn_tail(m->S.p, Lp, m->xraw.p, m->text.p, m->fscale, m->fshift, m->w_fc, m->w_fcp, logp, Tp, B, L, H2, c.num_class, st);
     }
 }
 
@@ -284,6 +300,7 @@ extern "C" int mdd_finalize_weights(mdd_model *m) {
         if ((rc = upload(m, tmp, &d))) return rc;
         m->wih.push_back(d);
         if (!pack_gate_rows(m, base, "weight_hh_l0", H, H, tmp)) return MDD_ERR_STATE;
+        if (use_packed(m)) { std::vector<float> pk; pack_whh(tmp, H, pk); tmp.swap(pk); }
         if ((rc = upload(m, tmp, &d))) return rc;
         m->whh.push_back(d);
         if (n > 0) {
@@ -299,6 +316,7 @@ extern "C" int mdd_finalize_weights(mdd_model *m) {
         if (!pack_gate_rows(m, "lstm_embeds.", "weight_ih_l0", H, c.emb_dim, tmp)) return MDD_ERR_STATE;
         if ((rc = upload(m, tmp, &m->t_wih))) return rc;
         if (!pack_gate_rows(m, "lstm_embeds.", "weight_hh_l0", H, H, tmp)) return MDD_ERR_STATE;
+        if (use_packed(m)) { std::vector<float> pk; pack_whh(tmp, H, pk); tmp.swap(pk); }
         if ((rc = upload(m, tmp, &m->t_whh))) return rc;
         std::vector<float> bi, bh;
         if (!pack_gate_rows(m, "lstm_embeds.", "bias_ih_l0", H, 1, bi) || !pack_gate_rows(m, "lstm_embeds.", "bias_hh_l0", H, 1, bh)) return MDD_ERR_STATE;
@@ -311,6 +329,21 @@ extern "C" int mdd_finalize_weights(mdd_model *m) {
         if (!bn_fold(m, "fc.0", 4 * H, sc, sh)) return MDD_ERR_STATE;
         if ((rc = upload(m, *ws, &m->w_score)) || (rc = upload(m, *wf, &m->w_fc)) || (rc = upload(m, sc, &m->fscale)) ||
             (rc = upload(m, sh, &m->fshift))) return rc;
+        m->w_fcp = nullptr;
+        const int D2 = 4 * H;
+        if (D2 % 64 == 0 && c.num_class <= 48) {   // consumer-order repack for attn_tail_mfma_kernel
+            const int J = D2 / 64;
+            std::vector<float> pk((size_t)4 * 3 * J * 64 * 4, 0.f);
+            for (int w = 0; w < 4; w++)
+                for (int nt = 0; nt < 3; nt++)
+                    for (int j = 0; j < J; j++)
+                        for (int lane = 0; lane < 64; lane++)
+                            for (int mm = 0; mm < 4; mm++) {
+                                const int n = nt * 16 + (lane & 15), k = w * (D2 / 4) + 16 * j + 4 * (lane >> 4) + mm;
+                                if (n < c.num_class) pk[((((size_t)w * 3 + nt) * J + j) * 64 + lane) * 4 + mm] = (*wf)[(size_t)n * D2 + k];
+                            }
+            if ((rc = upload(m, pk, &m->w_fcp))) return rc;
+        }
     }
     MDD_HIP_CHECK(hipDeviceSynchronize());
     m->finalized = true;
@@ -356,7 +389,7 @@ static int forward_prepare(mdd_model *m, const float *x_dev, int32_t B, int32_t 
     const size_t rows = (size_t)Tp * B, trows = (size_t)L * B, mrows = rows > trows ? rows : trows;
     if ((rc = ensure(m->y0, (size_t)B * c.channels * T * m->W1())) || (rc = ensure(m->seq0, rows * m->rnn_in())) ||
         (rc = ensure(m->gx, mrows * 8 * H)) || (rc = ensure(m->act[0], rows * 2 * H)) || (rc = ensure(m->act[1], rows * 2 * H)) ||
-        (rc = ensure(m->xraw, rows * 2 * H)) || (rc = ensure(m->hbuf, (size_t)4 * B * H)) || (rc = ensure(m->cbuf, (size_t)2 * B * H)) ||
+        (rc = ensure(m->xraw, rows * 2 * H)) || (rc = ensure(m->hbuf, (size_t)4 * ((B + 15) / 16 * 16) * H)) || (rc = ensure(m->cbuf, (size_t)2 * ((B + 15) / 16 * 16) * H)) ||
         (rc = ensure(m->embo, trows * c.emb_dim)) || (rc = ensure(m->text, trows * 2 * H)) || (rc = ensure(m->key, trows * 2 * H)) ||
         (rc = ensure(m->S, (size_t)B * Tp * L)))
         return rc;

@@ -113,8 +113,122 @@ __global__ __launch_bounds__(256) void attn_tail_kernel(const float *__restrict_
     }
 }
 
+// ---- MFMA variant (4H % 64 == 0): the context product and the classifier run on v_mfma_f32_16x16x4_f32.
+//   ctx[16 x 2H]  = attw[16 x L] . V_b[L x 2H]     : wave w owns column tiles w, w+4, ..
+//   logits[16x48] = y[16 x 4H] . Wfc^T             : K split over the 4 waves, partials summed through LDS
+// Wfc is repacked at weight-load time into the order the lanes consume it (zero rows for n >= C):
+//   wfcp[w][nt][j][lane][m] = Wfc[nt*16 + (lane&15)][w*(4H/4) + 16 j + 4 (lane>>4) + m]
+// dynamic LDS: attw[16][Lp] | y[16][D2 + 4] | part[4][16][48]
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(256) void attn_tail_mfma_kernel(const float *__restrict__ S, int Lp, const float *__restrict__ X,
+                                                             const float *__restrict__ V, const float *__restrict__ fscale,
+                                                             const float *__restrict__ fshift, const float *__restrict__ wfcp,
+                                                             float *__restrict__ logp, int Tp, int B, int L, int H2, int C) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int D2 = 2 * H2, LDY = D2 + 4, LA = (L + 3) & ~3;
+    float *attw = smem;                  // [16][LA]
+    float *y = attw + 16 * LA;           // [16][LDY]
+    float *part = y + 16 * LDY;          // [4][16][48]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, kq = lane >> 4;
+    const int b = blockIdx.y, t0 = blockIdx.x * 16;
+    const int nt_rows = min(16, Tp - t0);
+
+    // 1. softmax over L (one wave per row); padded rows / columns are zero
+    for (int r = wave; r < 16; r += 4) {
+        float *arow = attw + r * LA;
+        if (r >= nt_rows) { for (int l = lane; l < LA; l += 64) arow[l] = 0.f; continue; }
+        const float *srow = S + ((size_t)b * Tp + t0 + r) * Lp;
+        float mx = -INFINITY;
+        for (int l = lane; l < L; l += 64) mx = fmaxf(mx, srow[l]);
+        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+        float sum = 0.f;
+        for (int l = lane; l < LA; l += 64) { float e = l < L ? expf(srow[l] - mx) : 0.f; arow[l] = e; sum += e; }
+        for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+        for (int l = lane; l < L; l += 64) arow[l] = arow[l] / sum;
+    }
+    // x half of y = BN(X)
+    for (int i = tid; i < 16 * H2; i += 256) {
+        const int r = i / H2, d = i - r * H2;
+        const float xv = r < nt_rows ? X[((size_t)(t0 + r) * B + b) * H2 + d] : 0.f;
+        y[r * LDY + d] = xv * fscale[d] + fshift[d];
+    }
+    __syncthreads();
+
+    // 2. ctx tiles: A = attw[row li][k], B = V[k = l][col d]
+    for (int nt = wave; nt * 16 < H2; nt += 4) {
+        const int d = nt * 16 + li;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int ks = 0; ks < LA; ks += 4) {
+            const int l = ks + kq;
+            const float a = attw[li * LA + l];
+            const float v = V[((size_t)(l < L ? l : L - 1) * B + b) * H2 + d];   // attw is 0 for l >= L
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, v, acc, 0, 0, 0);
+        }
+        const float sc = fscale[H2 + d], hc = fshift[H2 + d];
+#pragma unroll
+        for (int r = 0; r < 4; r++) y[(kq * 4 + r) * LDY + H2 + d] = acc[r] * sc + hc;   // D: row = 4*(lane>>4)+r, col = lane&15
+    }
+    __syncthreads();
+
+    // 3. classifier: this wave's quarter of K, three 16-column tiles
+    {
+        const int J = D2 / 64;   // float4 groups per wave quarter
+        const float4 *wp = reinterpret_cast<const float4 *>(wfcp) + (size_t)wave * 3 * J * 64 + lane;
+        const float *yr = y + li * LDY + wave * (D2 / 4) + 4 * kq;
+        f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0;
+#pragma unroll 4
+        for (int j = 0; j < J; j++) {
+            const float4 y4 = *reinterpret_cast<const float4 *>(yr + 16 * j);
+            const float4 w0 = wp[(0 * J + j) * 64], w1 = wp[(1 * J + j) * 64], w2 = wp[(2 * J + j) * 64];
+            a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(y4.x, w0.x, a0, 0, 0, 0);
+            a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(y4.x, w1.x, a1, 0, 0, 0);
+            a2 = __builtin_amdgcn_mfma_f32_16x16x4f32(y4.x, w2.x, a2, 0, 0, 0);
+            a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(y4.y, w0.y, a0, 0, 0, 0);
+            a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(y4.y, w1.y, a1, 0, 0, 0);
+            a2 = __builtin_amdgcn_mfma_f32_16x16x4f32(y4.y, w2.y, a2, 0, 0, 0);
+            a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(y4.z, w0.z, a0, 0, 0, 0);
+            a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(y4.z, w1.z, a1, 0, 0, 0);
+            a2 = __builtin_amdgcn_mfma_f32_16x16x4f32(y4.z, w2.z, a2, 0, 0, 0);
+            a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(y4.w, w0.w, a0, 0, 0, 0);
+            a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(y4.w, w1.w, a1, 0, 0, 0);
+            a2 = __builtin_amdgcn_mfma_f32_16x16x4f32(y4.w, w2.w, a2, 0, 0, 0);
+        }
+        float *pw = part + wave * 16 * 48;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {   // D: row (time) = 4*(lane>>4)+r, col (class) = lane&15
+            pw[(kq * 4 + r) * 48 + li] = a0[r];
+            pw[(kq * 4 + r) * 48 + 16 + li] = a1[r];
+            pw[(kq * 4 + r) * 48 + 32 + li] = a2[r];
+        }
+    }
+    __syncthreads();
+
+    // 4. sum the four K-quarters, log-softmax over C (one wave per row)
+    for (int r = wave; r < nt_rows; r += 4) {
+        float v = -INFINITY;
+        if (lane < C) v = (part[r * 48 + lane] + part[(16 + r) * 48 + lane]) + (part[(32 + r) * 48 + lane] + part[(48 + r) * 48 + lane]);
+        float mx = v;
+        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+        float sum = lane < C ? expf(v - mx) : 0.f;
+        for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+        const float lse = logf(sum);
+        if (lane < C) logp[((size_t)(t0 + r) * B + b) * C + lane] = (v - mx) - lse;
+    }
+}
+
 int launch_attn_tail(const float *S, int Lp, const float *X, const float *V, const float *fscale, const float *fshift,
-                     const float *wfc, float *logp, int Tp, int B, int L, int H2, int C, hipStream_t st) {
+                     const float *wfc, const float *wfcp, float *logp, int Tp, int B, int L, int H2, int C, hipStream_t st) {
+    if (wfcp && (2 * H2) % 64 == 0 && C <= 48) {
+        const int D2 = 2 * H2, LA = (L + 3) & ~3;
+        size_t smem = sizeof(float) * ((size_t)16 * LA + (size_t)16 * (D2 + 4) + 4 * 16 * 48);
+        if (smem > 160 * 1024) { set_error("attn_tail: L=%d too long for the LDS tile (%zu B)", L, smem); return MDD_ERR_ARG; }
+        hipLaunchKernelGGL(attn_tail_mfma_kernel, dim3((Tp + 15) / 16, B), dim3(256), smem, st, S, Lp, X, V, fscale, fshift, wfcp,
+                           logp, Tp, B, L, H2, C);
+        MDD_LAUNCH_CHECK();
+        return MDD_OK;
+    }
     if (H2 % 2 != 0) { set_error("attn_tail: 2H must be even"); return MDD_ERR_ARG; }
     size_t smem = sizeof(float) * ((size_t)TT * L + (size_t)TT * 2 * H2 + (size_t)TT * C);
     if (smem > 160 * 1024) { set_error("attn_tail: L=%d too long for the LDS tile (%zu B)", L, smem); return MDD_ERR_ARG; }
@@ -127,6 +241,7 @@ int launch_attn_tail(const float *S, int Lp, const float *X, const float *V, con
 
 int init_kernel_attributes() {  // called once from mdd_create (never inside a stream capture)
     MDD_HIP_CHECK(hipFuncSetAttribute((const void *)attn_tail_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    MDD_HIP_CHECK(hipFuncSetAttribute((const void *)attn_tail_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     return MDD_OK;
 }
 

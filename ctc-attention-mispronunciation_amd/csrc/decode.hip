@@ -78,18 +78,50 @@ __device__ __forceinline__ void wave_argmax(double &v, int &ord) {
     }
 }
 
-// One wave per utterance.  dynamic LDS layout (bytes):
-//   tot[beam*C] double | lp[C] double | p[C] float | prefix[2][beam][Tcap] uint8
-__global__ __launch_bounds__(64) void beam_kernel(const float *__restrict__ logp, int T, int B, int C,
-                                                  const int32_t *__restrict__ len, int beam, int blank,
+// ---- pass 1 (parallel over frames): everything about a frame that does not depend on the beam state.
+//   lp[t,b,c]   = log((double)p) with p = fp32(exp(logp))   (-inf where p == 0: the reference raises ValueError
+//                 when such a value is needed, BeamSearch.py:64,66,103,106)
+//   flags[t,b]  bit0: frame is live, i.e. NOT (1 - p_blank < 0.1) in float32 (BeamSearch.py:93-94)
+//               bit1: p_blank of the raw previous frame < 0.9 in float32 (the repeat rule, :63)
+// exp() is evaluated in fp64 and rounded once, so p is the correctly rounded fp32 value the reference's
+// torch.exp (ctcDecoder.py:224) produces on ~99% of inputs (<= 1 ulp otherwise).
+__global__ __launch_bounds__(256) void beam_prep_kernel(const float *__restrict__ logp, int T, int B, int C, int blank,
+                                                        double *__restrict__ lp, unsigned char *__restrict__ flags) {
+    const size_t n = (size_t)T * B * C;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float p = (float)exp((double)logp[i]);
+        lp[i] = p > 0.0f ? log((double)p) : -INFINITY;
+        const size_t tb = i / C;
+        if ((int)(i - tb * C) == blank) {
+            unsigned char f = ((1.0f - p) < 0.1f) ? 0 : 1;
+            const size_t t = tb / B;
+            if (t > 0) {
+                const float pprev = (float)exp((double)logp[i - (size_t)B * C]);
+                if (pprev < 0.9f) f |= 2;
+            }
+            flags[tb] = f;
+        }
+    }
+}
+
+// ---- pass 2: one wave per utterance, serial over the live frames.  dynamic LDS layout (bytes):
+//   tot[beam*C] double | lmt[(C+1)*(C+1)] double (if it fits) | cl_v[beam*C] double | cl_o[beam*C] int |
+//   flags[Tcap] uint8 | prefix[2][beam][Tcap] uint8
+__global__ __launch_bounds__(64) void beam_kernel(const double *__restrict__ lpw, const unsigned char *__restrict__ flags,
+                                                  int T, int B, int C, const int32_t *__restrict__ len, int beam, int blank,
                                                   const double *__restrict__ lm, double alpha, int32_t *__restrict__ ids,
                                                   int32_t *__restrict__ nids, int32_t *__restrict__ status,
-                                                  double *__restrict__ score, int Tcap) {
+                                                  double *__restrict__ score, int Tcap, int lm_in_lds, int skip, long long *dbg) {
     extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
+    const int C1 = C + 1;
     double *tot = reinterpret_cast<double *>(sm);
-    double *lp = tot + (size_t)beam * C;
-    float *p = reinterpret_cast<float *>(lp + C);
-    unsigned char *pref = reinterpret_cast<unsigned char *>(p + ((C + 3) & ~3));
+    double *lmt = tot + (size_t)beam * C;
+    double *cl_v = lmt + (lm_in_lds ? C1 * C1 : 0);                  // compacted candidate list (values)
+    int *cl_o = reinterpret_cast<int *>(cl_v + (size_t)beam * C);    //   and their insertion orders
+    unsigned char *fl = reinterpret_cast<unsigned char *>(cl_o + (size_t)beam * C);  // per-frame flags of this utterance [Tcap]
+    unsigned char *pref = fl + Tcap;
+    __shared__ double lp[256];
+    __shared__ int nlist;
     __shared__ BeamMeta meta[2][MAXBEAM];
     __shared__ double cNB[MAXBEAM], cB[MAXBEAM], cT[MAXBEAM];  // copy-path contributions per beam
     __shared__ int parent[MAXBEAM], mslot[MAXBEAM];             // parent beam index / ext slot merged with this beam's copy
@@ -97,73 +129,100 @@ __global__ __launch_bounds__(64) void beam_kernel(const float *__restrict__ logp
     __shared__ int sel_ord[MAXBEAM];
 
     const int b = blockIdx.x, lane = threadIdx.x;
-    const int C1 = C + 1;
     int cur = 0, nb = 1, err = 0;
+    long long ph[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tstamp = 0;
+#define STAMP(i) do { if (dbg) { long long now_ = __builtin_readcyclecounter(); ph[i] += now_ - tstamp; tstamp = now_; } } while (0)
     if (lane == 0) {
         BeamMeta &m = meta[0][0];
         m.prTotal = 0.0; m.prBlank = 0.0; m.prNonBlank = LOG_ZERO; m.len = 0; m.last = -1;
         m.hash = 0x243F6A8885A308D3ull; m.phash = 0;
     }
+    if (lm_in_lds) for (int i = lane; i < C1 * C1; i += 64) lmt[i] = lm[i];
+    const double *lmp = lm_in_lds ? lmt : lm;
     __syncthreads();
     int tl = len[b];
     tl = tl < 0 ? 0 : (tl > T ? T : tl);
+    for (int i = lane; i < tl; i += 64) fl[i] = flags[(size_t)i * B + b];
+    __syncthreads();
 
-    for (int t = 0; t < tl; t++) {
-        const float *row = logp + ((size_t)t * B + b) * C;
-        // probabilities as the reference sees them: exp() of the fp32 log-prob, rounded to fp32
-        // (ctcDecoder.py:224); computed in fp64 then rounded so the fp32 value is correctly rounded.
-        const float pblank = (float)exp((double)row[blank]);
-        if ((1.0f - pblank) < 0.1f) continue;  // BeamSearch.py:93-94 (float32 compare); wave-uniform
-        for (int c = lane; c < C; c += 64) {
-            const float pc = (float)exp((double)row[c]);
-            p[c] = pc;
-            lp[c] = pc > 0.0f ? log((double)pc) : 0.0;
-        }
-        float pprevb = 0.f;
-        if (t > 0) pprevb = (float)exp((double)logp[((size_t)(t - 1) * B + b) * C + blank]);  // raw previous row (:63)
+    // software prefetch: the row of the next live frame is loaded while the current one is processed
+    int t = 0;
+    while (t < tl && !(fl[t] & 1)) t++;
+    double pre[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) pre[i] = (t < tl && lane + 64 * i < C) ? lpw[((size_t)t * B + b) * C + lane + 64 * i] : 0.0;
+    if (dbg) tstamp = __builtin_readcyclecounter();
+    while (t < tl) {
+        const bool rep_ok = (fl[t] & 2) != 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) if (lane + 64 * i < C) lp[lane + 64 * i] = pre[i];
+        int tn = t + 1;
+        while (tn < tl && !(fl[tn] & 1)) tn++;
+#pragma unroll
+        for (int i = 0; i < 4; i++) pre[i] = (tn < tl && lane + 64 * i < C) ? lpw[((size_t)tn * B + b) * C + lane + 64 * i] : 0.0;
         __syncthreads();
         const BeamMeta *last = meta[cur];
         unsigned char *pcur = pref + (size_t)cur * beam * Tcap, *pnext = pref + (size_t)(cur ^ 1) * beam * Tcap;
 
-        // ---- candidate scores.  slot idx = r*C + k ; k == blank is beam r's own ("copy") entry
+        STAMP(0);
+        // ---- candidate scores.  slot idx = r*C + k ; k == blank is beam r's own ("copy") entry.
+        // lanes own the class index k (k = lane, lane+64, ..), the beam rank r is a uniform loop.
         int first_err_ord = 0x7fffffff, first_err = 0;
-        for (int idx = lane; idx < nb * C; idx += 64) {
-            const int r = idx / C, k = idx - r * C;
-            if (k == blank) continue;
+        for (int r = 0; r < nb && !(skip & 1); r++) {
             const BeamMeta &y = last[r];
-            const double lmv = lm[(size_t)(y.len ? y.last : C) * C1 + k];  // consulted even when alpha == 0 (:57-60)
-            const int ord = r * C1 + 1 + k;
-            if (lmv != lmv) { if (ord < first_err_ord) { first_err_ord = ord; first_err = MDD_BEAM_KEY_ERROR; } }
-            else if (p[k] == 0.0f) { if (ord < first_err_ord) { first_err_ord = ord; first_err = MDD_BEAM_VALUE_ERROR; } }
-            const double bigram = lmv * alpha;
-            const double base = (y.len && y.last == k && pprevb < 0.9f) ? y.prBlank : y.prTotal;  // :63-66
-            tot[idx] = lp[k] + bigram + base;
+            const int ylen = y.len, ylast = y.last;
+            const double yB = y.prBlank, yT = y.prTotal;
+            const double *lmrow = lmp + (ylen ? ylast : C) * C1;
+            for (int k = lane; k < C; k += 64) {
+                if (k == blank) continue;
+                const double lmv = lmrow[k];  // consulted even when alpha == 0 (:57-60)
+                const double lk = lp[k];
+                const int ord = r * C1 + 1 + k;
+                if (lmv != lmv) { if (ord < first_err_ord) { first_err_ord = ord; first_err = MDD_BEAM_KEY_ERROR; } }
+                else if (lk == -INFINITY) { if (ord < first_err_ord) { first_err_ord = ord; first_err = MDD_BEAM_VALUE_ERROR; } }
+                const double base = (ylen && ylast == k && rep_ok) ? yB : yT;  // :63-66
+                tot[r * C + k] = lk + lmv * alpha + base;
+            }
         }
+        STAMP(1);
         if (lane < nb) {
             const BeamMeta &y = last[lane];
             double pnb = LOG_ZERO;
-            bool bad = (p[blank] == 0.0f);
-            if (y.len > 0) { pnb = y.prNonBlank + lp[y.last]; bad = bad || (p[y.last] == 0.0f); }  // :103
-            const double pb = y.prTotal + lp[blank];                                                // :106
+            bool bad = (lp[blank] == -INFINITY);
+            if (y.len > 0) { pnb = y.prNonBlank + lp[y.last]; bad = bad || (lp[y.last] == -INFINITY); }  // :103
+            const double pb = y.prTotal + lp[blank];                                                      // :106
             if (bad) { const int ord = lane * C1; if (ord < first_err_ord) { first_err_ord = ord; first_err = MDD_BEAM_VALUE_ERROR; } }
             cNB[lane] = pnb; cB[lane] = pb;
-            const double tc = log_add_prob(pb, pnb);                                                // :112
+            const double tc = (skip & 2) ? pb : log_add_prob(pb, pnb);                                   // :112
             cT[lane] = tc;
             tot[lane * C + blank] = tc;
-            // parent search: y_q == y[:-1] ?
+            // parent candidate: a beam q whose (length, hash) equal those of y without its last symbol
             int par = -1;
-            if (y.len > 0) {
-                for (int q = 0; q < nb; q++) {
-                    if (q == lane || last[q].len != y.len - 1 || last[q].hash != y.phash) continue;
-                    bool same = true;  // verify the content (hash collisions must not merge distinct prefixes)
-                    const unsigned char *pa = pcur + (size_t)lane * Tcap, *pq = pcur + (size_t)q * Tcap;
-                    for (int i = 0; i < y.len - 1; i++) if (pa[i] != pq[i]) { same = false; break; }
-                    if (same) { par = q; break; }
-                }
-            }
+            if (y.len > 0)
+                for (int q = 0; q < nb; q++)
+                    if (q != lane && last[q].len == y.len - 1 && last[q].hash == y.phash) { par = q; break; }
             parent[lane] = par;
             mslot[lane] = -1;
         }
+        STAMP(2);
+        // verify the content of every hash match with the whole wave (a hash collision must never merge two
+        // distinct prefixes): 64 lanes compare 64 words per pass, the tail word is masked to the prefix length
+        for (int a = 0; a < nb && !(skip & 4); a++) {
+            const int q = parent[a];          // uniform (LDS broadcast; written by lane a above, same wave, in order)
+            if (q < 0) continue;
+            const int ln = last[q].len;
+            const unsigned int *wa = reinterpret_cast<const unsigned int *>(pcur + (size_t)a * Tcap);
+            const unsigned int *wq = reinterpret_cast<const unsigned int *>(pcur + (size_t)q * Tcap);
+            bool neq = false;
+            for (int j = lane; j * 4 < ln; j += 64) {
+                unsigned int x = wa[j] ^ wq[j];
+                const int rem = ln - j * 4;
+                if (rem < 4) x &= (1u << (8 * rem)) - 1u;
+                neq = neq || (x != 0);
+            }
+            if (__any(neq) && lane == 0) parent[a] = -1;
+        }
+        STAMP(3);
         {   // first error in the reference's execution order wins
             int eo = first_err_ord;
             for (int o = 32; o > 0; o >>= 1) eo = min(eo, __shfl_xor(eo, o));
@@ -176,7 +235,7 @@ __global__ __launch_bounds__(64) void beam_kernel(const float *__restrict__ logp
         __syncthreads();
         // ---- merges: beam a's copy entry and its parent's extension by a's last symbol are one dict entry
         int nmerge = 0;
-        if (lane < nb && parent[lane] >= 0) {
+        if (lane < nb && parent[lane] >= 0 && !(skip & 8)) {
             const int a = lane, q = parent[a], e = q * C + last[a].last;
             const double pr = tot[e];
             if (q < a) {  // entry was created by the extension (inserted earlier), then the copy is added (:108-113)
@@ -195,38 +254,76 @@ __global__ __launch_bounds__(64) void beam_kernel(const float *__restrict__ logp
         }
         nmerge = __popcll(__ballot(nmerge != 0));
         __syncthreads();
+        STAMP(4);
         // ---- `last.sort()[0:beam]`: stable, descending by prTotal; insertion order = (r, copy first, then k ascending)
         const int ncand = nb * C - nmerge;
         const int keep = ncand < beam ? ncand : beam;
-        double lv = -INFINITY;
-        int lord = 0x7fffffff;
-        auto ord_of = [&](int idx) { const int r = idx / C, k = idx - r * C; return r * C + (k == blank ? 0 : (k < blank ? k + 1 : k)); };
-        auto idx_of = [&](int ord) { const int r = ord / C, j = ord - r * C; return r * C + (j == 0 ? blank : (j <= blank ? j - 1 : j)); };
-        for (int idx = lane; idx < nb * C; idx += 64) {
-            const double v = tot[idx];
-            const int o = ord_of(idx);
-            if (v > lv || (v == lv && o < lord)) { lv = v; lord = o; }
-        }
-        for (int i = 0; i < keep; i++) {
-            double v = lv; int o = lord;
-            wave_argmax(v, o);
-            if (lane == 0) { sel_v[i] = v; sel_ord[i] = o; }
-            if (o == lord && lord != 0x7fffffff) {  // this lane owned the winner: retire it and rescan its slots
-                tot[idx_of(o)] = -INFINITY;
-                lv = -INFINITY; lord = 0x7fffffff;
-                for (int idx = lane; idx < nb * C; idx += 64) {
-                    const double v2 = tot[idx];
-                    const int o2 = ord_of(idx);
-                    if (v2 > lv || (v2 == lv && o2 < lord)) { lv = v2; lord = o2; }
+        // Top-`keep` of the <= nb*C candidates under (value desc, insertion order asc) without serial pops:
+        //  1. theta0 = keep-th largest of the 64 per-lane maxima (rank counting over v_readlane broadcasts); at
+        //     least `keep` candidates are >= theta0, so every member of the true top-`keep` is too;
+        //  2. the few candidates >= theta0 are compacted into an LDS list (order irrelevant);
+        //  3. each list entry counts the entries that beat it; rank < keep -> it IS output position `rank`.
+        // insertion order of slot (r,k): r*C + (k == blank ? 0 : (k < blank ? k+1 : k)).
+        const float invC = 1.0f / (float)C;
+        auto idx_of = [&](int ord) {
+            const int r = (int)(((float)ord + 0.5f) * invC), j = ord - r * C;
+            return r * C + (j == 0 ? blank : (j <= blank ? j - 1 : j));
+        };
+        if (!(skip & 16)) {
+            double lmax = -INFINITY;
+            for (int r = 0; r < nb; r++)
+                for (int k = lane; k < C; k += 64) lmax = fmax(lmax, tot[r * C + k]);
+            STAMP(5);
+            int rk = 0;
+            {
+                const int lo = __double2loint(lmax), hi = __double2hiint(lmax);
+#pragma unroll 8
+                for (int j = 0; j < 64; j++) {
+                    const double sj = __hiloint2double(__builtin_amdgcn_readlane(hi, j), __builtin_amdgcn_readlane(lo, j));
+                    rk += (sj > lmax || (sj == lmax && j < lane)) ? 1 : 0;
                 }
             }
-        }
+            const unsigned long long mk = __ballot(rk == keep - 1);
+            const int srcl = __ffsll((long long)mk) - 1;
+            const double theta0 = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(lmax), srcl),
+                                                   __builtin_amdgcn_readlane(__double2loint(lmax), srcl));
+            STAMP(6);
+            if (lane == 0) nlist = 0;
+            __syncthreads();
+            if (lmax >= theta0) {
+                int cnt = 0;
+                for (int r = 0; r < nb; r++)
+                    for (int k = lane; k < C; k += 64) cnt += (tot[r * C + k] >= theta0) ? 1 : 0;
+                int pos = atomicAdd(&nlist, cnt);
+                for (int r = 0; r < nb; r++)
+                    for (int k = lane; k < C; k += 64) {
+                        const double v = tot[r * C + k];
+                        if (v >= theta0) { cl_v[pos] = v; cl_o[pos] = r * C + (k == blank ? 0 : (k < blank ? k + 1 : k)); pos++; }
+                    }
+            }
+            __syncthreads();
+            const int nl = nlist;
+            STAMP(7);
+            if (dbg) ph[9] += nl;
+            for (int e = lane; e < nl; e += 64) {
+                const double v = cl_v[e];
+                const int o = cl_o[e];
+                int rank = 0;
+                for (int f = 0; f < nl; f++) {
+                    const double vf = cl_v[f];
+                    const int of = cl_o[f];
+                    rank += (vf > v || (vf == v && of < o)) ? 1 : 0;
+                }
+                if (rank < keep) { sel_v[rank] = v; sel_ord[rank] = idx_of(o); }
+            }
+        } else if (lane < keep) { sel_v[lane] = 0.0; sel_ord[lane] = lane * C + 1; }
         __syncthreads();
+        STAMP(8);
         // ---- materialise the new beams
         BeamMeta *next = meta[cur ^ 1];
         if (lane < keep) {
-            const int idx = idx_of(sel_ord[lane]);
-            const int r = idx / C, k = idx - r * C;
+            const int idx = sel_ord[lane];
+            const int r = (int)(((float)idx + 0.5f) * invC), k = idx - r * C;
             const BeamMeta &y = last[r];
             BeamMeta n;
             if (k == blank) {
@@ -241,19 +338,23 @@ __global__ __launch_bounds__(64) void beam_kernel(const float *__restrict__ logp
             }
             next[lane] = n;
         }
-        for (int i = 0; i < keep; i++) {
-            const int idx = idx_of(sel_ord[i]);
-            const int r = idx / C, k = idx - r * C;
+        for (int i = 0; i < keep && !(skip & 32); i++) {
+            const int idx = sel_ord[i];
+            const int r = (int)(((float)idx + 0.5f) * invC), k = idx - r * C;
             const int ln = last[r].len;
-            const unsigned char *src = pcur + (size_t)r * Tcap;
-            unsigned char *dst = pnext + (size_t)i * Tcap;
-            for (int j = lane; j < ln; j += 64) dst[j] = src[j];
-            if (k != blank && lane == 0) dst[ln] = (unsigned char)k;
+            const unsigned int *src = reinterpret_cast<const unsigned int *>(pcur + (size_t)r * Tcap);
+            unsigned int *dst = reinterpret_cast<unsigned int *>(pnext + (size_t)i * Tcap);
+            for (int j = lane; j * 4 < ln; j += 64) dst[j] = src[j];      // Tcap % 4 == 0: whole words
+            __builtin_amdgcn_wave_barrier();
+            if (k != blank && lane == 0) reinterpret_cast<unsigned char *>(dst)[ln] = (unsigned char)k;
         }
         __syncthreads();
         cur ^= 1;
         nb = keep;
+        t = tn;
+        if (dbg) tstamp = __builtin_readcyclecounter();
     }
+    if (dbg && lane == 0) for (int i = 0; i < 10; i++) dbg[b * 10 + i] = ph[i];
     __syncthreads();
     // ---- final: EOS LM term, length normalisation, first maximum (:130-148)
     if (lane == 0) {
@@ -263,7 +364,7 @@ __global__ __launch_bounds__(64) void beam_kernel(const float *__restrict__ logp
         for (int r = 0; r < nb && !err; r++) {
             const BeamMeta &y = last[r];
             if (y.len == 0) { err = MDD_BEAM_INDEX_ERROR; break; }   // y[-1] on the empty tuple (:135)
-            const double v = lm[(size_t)y.last * C1 + C];
+            const double v = lmp[y.last * C1 + C];
             if (v != v) { err = MDD_BEAM_KEY_ERROR; break; }
             double pr = log_add_prob(LOG_ZERO, y.prTotal + v * alpha);
             pr = pr * (1.0 / (double)(y.len ? y.len : 1));
@@ -304,16 +405,32 @@ extern "C" int mdd_beam(const float *logp_dev, int32_t T, int32_t B, int32_t C, 
         C > 256 || beam < 1 || beam > MAXBEAM || blank < 0 || blank >= C) {
         set_error("mdd_beam: bad argument (need 1<=beam<=64, 2<=C<=256)"); return MDD_ERR_ARG;
     }
+    hipStream_t st = (hipStream_t)stream;
     const int Tcap = (T + 1 + 3) & ~3;
-    size_t smem = sizeof(double) * ((size_t)beam * C + C) + sizeof(float) * ((C + 3) & ~3) + (size_t)2 * beam * Tcap;
+    const size_t lm_bytes = sizeof(double) * (size_t)(C + 1) * (C + 1);
+    const size_t base = (sizeof(double) * 2 + sizeof(int)) * (size_t)beam * C + (size_t)(2 * beam + 1) * Tcap;
+    const int lm_in_lds = (base + lm_bytes <= 96 * 1024) ? 1 : 0;
+    const size_t smem = base + (lm_in_lds ? lm_bytes : 0);
     if (smem > 140 * 1024) { set_error("mdd_beam: beam*C / T too large for LDS (%zu B)", smem); return MDD_ERR_ARG; }
     static bool attr_set = false;
     if (!attr_set) {
         MDD_HIP_CHECK(hipFuncSetAttribute((const void *)beam_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
         attr_set = true;
     }
-    hipLaunchKernelGGL(beam_kernel, dim3(B), dim3(64), smem, (hipStream_t)stream, logp_dev, T, B, C, len_dev, beam, blank,
-                       lm_dev, lm_alpha, ids_dev, nids_dev, status_dev, score_dev, Tcap);
-    MDD_LAUNCH_CHECK();
+    // stream-ordered scratch for the frame pre-pass: log-probabilities in fp64 + per-frame flags
+    double *lpw = nullptr;
+    unsigned char *flags = nullptr;
+    const size_t n = (size_t)T * B * C;
+    MDD_HIP_CHECK(hipMallocAsync((void **)&lpw, n * sizeof(double) + (size_t)T * B, st));
+    flags = reinterpret_cast<unsigned char *>(lpw + n);
+    int grid = (int)((n + 255) / 256);
+    if (grid > 2048) grid = 2048;
+    hipLaunchKernelGGL(beam_prep_kernel, dim3(grid), dim3(256), 0, st, logp_dev, T, B, C, blank, lpw, flags);
+    hipLaunchKernelGGL(beam_kernel, dim3(B), dim3(64), smem, st, lpw, flags, T, B, C, len_dev, beam, blank, lm_dev, lm_alpha,
+                       ids_dev, nids_dev, status_dev, score_dev, Tcap, lm_in_lds, getenv("MDD_BEAM_SKIP") ? atoi(getenv("MDD_BEAM_SKIP")) : 0,
+                       getenv("MDD_BEAM_DBG") ? reinterpret_cast<long long *>(score_dev) + B : nullptr);
+    hipError_t le = hipGetLastError();
+    (void)hipFreeAsync(lpw, st);
+    if (le != hipSuccess) { set_error("beam kernel launch failed: %s", hipGetErrorString(le)); return MDD_ERR_HIP; }
     return MDD_OK;
 }

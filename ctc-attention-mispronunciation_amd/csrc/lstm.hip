@@ -24,6 +24,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float sigmoid_f(float v) { return 1.f / (1.f + expf(-v)); }
 
+// ---- generic variant (any H % 4 == 0; row-major Whh', h and c): used for small test geometries
 template <bool VEC>
 __global__ __launch_bounds__(256) void lstm_step_kernel(LstmStepArgs a, int s) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -73,12 +74,76 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(LstmStepArgs a, int s) {
     }
 }
 
+// ---- packed variant (H % 16 == 0): every global access of the k-loop is a fully coalesced 1 KB read.
+// Whh is repacked at weight-load time into the exact order the lanes consume it,
+//   Wp[d][ut][j][lane][m] = Whh'[d][ut*16 + (lane&15)][16 j + 4 (lane>>4) + m]
+// and h is exchanged between steps in the same consumer order,
+//   hp[parity][d][bt][j][lane][m] = h[bt*16 + (lane&15)][16 j + 4 (lane>>4) + m]
+// (a producer wave owns k = 4 ut .. 4 ut+3 for 16 batch rows: 64 contiguous floats), and c lives in
+// producer order cp[d][bt][ut][lane].  Four independent accumulators (one per float4 component) keep
+// the MFMA pipe at its 32-cycle issue rate instead of the 40-cycle dependent latency.
+template <int J>
+__global__ __launch_bounds__(256, 1) void lstm_step_packed_kernel(LstmStepArgs a, int s) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int ut = blockIdx.x, d = blockIdx.y;
+    const int NBT = (a.B + 15) >> 4, NUT = a.H >> 2;
+    const int bt = blockIdx.z * 4 + wave;
+    if (bt >= NBT) return;  // wave-uniform
+    const int H = a.H, B = a.B;
+    const int t = d ? (a.T - 1 - s) : s;
+    const int li = lane & 15, uu = lane >> 4;
+    const int b = bt * 16 + li, u = ut * 4 + uu;
+    const size_t hplane = (size_t)2 * NBT * J * 256;  // floats per parity
+    const float4 *hp = reinterpret_cast<const float4 *>(a.hbuf + ((s & 1) ^ 1) * hplane) + ((size_t)(d * NBT + bt) * J) * 64 + lane;
+    const float4 *wp = reinterpret_cast<const float4 *>(a.whh) + ((size_t)(d * NUT + ut) * J) * 64 + lane;
+    const size_t ci = ((size_t)(d * NBT + bt) * NUT + ut) * 64 + lane;
+
+    float4 g4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float cold = 0.f;
+    if (b < B) {
+        g4 = *reinterpret_cast<const float4 *>(a.gx + (((size_t)t * B + b) * 2 + d) * 4 * H + u * 4);
+        if (s > 0) cold = a.cbuf[ci];
+    }
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0, acc2 = acc0, acc3 = acc0;
+    if (s > 0) {
+        float4 w4[J], h4[J];
+#pragma unroll
+        for (int j = 0; j < J; j++) { w4[j] = wp[j * 64]; h4[j] = hp[j * 64]; }
+        // keep every load ahead of the first MFMA: the whole k-panel (2 x J KB per wave) is in flight at once,
+        // so the step pays ONE L2 round trip instead of one per k-slice (hipcc otherwise sinks the loads)
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < J; j++) {
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w4[j].x, h4[j].x, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w4[j].y, h4[j].y, acc1, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(w4[j].z, h4[j].z, acc2, 0, 0, 0);
+            acc3 = __builtin_amdgcn_mfma_f32_16x16x4f32(w4[j].w, h4[j].w, acc3, 0, 0, 0);
+        }
+    }
+    if (b < B) {
+        const float gi = (acc0[0] + acc1[0]) + (acc2[0] + acc3[0]) + g4.x;
+        const float gf = (acc0[1] + acc1[1]) + (acc2[1] + acc3[1]) + g4.y;
+        const float gg = (acc0[2] + acc1[2]) + (acc2[2] + acc3[2]) + g4.z;
+        const float go = (acc0[3] + acc1[3]) + (acc2[3] + acc3[3]) + g4.w;
+        const float ig = sigmoid_f(gi), fg = sigmoid_f(gf), cg = tanhf(gg), og = sigmoid_f(go);
+        const float cn = fg * cold + ig * cg;
+        const float hn = og * tanhf(cn);
+        a.cbuf[ci] = cn;
+        float *hnext = a.hbuf + (s & 1) * hplane;
+        hnext[(((size_t)(d * NBT + bt) * J + (ut >> 2)) * 64 + (ut & 3) * 16 + li) * 4 + uu] = hn;
+        const size_t oi = ((size_t)t * B + b) * 2 * H + d * H + u;
+        if (a.out_raw) a.out_raw[oi] = hn;
+        if (a.out != a.out_raw) a.out[oi] = a.oscale ? hn * a.oscale[d * H + u] + a.oshift[d * H + u] : hn;
+    }
+}
+
 int launch_lstm_layer(const LstmStepArgs &a, hipStream_t st) {
     if (a.H % 4 != 0 || a.T <= 0 || a.B <= 0) { set_error("lstm: bad shape T=%d B=%d H=%d", a.T, a.B, a.H); return MDD_ERR_ARG; }
     dim3 grid(a.H / 4, 2, (a.B + 63) / 64), block(256);
-    const bool vec = (a.H % 16 == 0);
     for (int s = 0; s < a.T; s++) {
-        if (vec) hipLaunchKernelGGL(lstm_step_kernel<true>, grid, block, 0, st, a, s);
+        if (a.packed && a.H == 384) hipLaunchKernelGGL(lstm_step_packed_kernel<24>, grid, block, 0, st, a, s);
+        else if (a.packed && a.H == 256) hipLaunchKernelGGL(lstm_step_packed_kernel<16>, grid, block, 0, st, a, s);
+        else if (a.packed) { set_error("lstm: packed layout built for H in {256,384}"); return MDD_ERR_ARG; }
         else hipLaunchKernelGGL(lstm_step_kernel<false>, grid, block, 0, st, a, s);
     }
     MDD_LAUNCH_CHECK();

@@ -48,6 +48,7 @@ struct LstmStepArgs {
     const float *oscale; // [2H] (nullable -> identity)
     const float *oshift;
     int T, B, H;
+    int packed;          // 1: whh / hbuf / cbuf use the packed consumer layouts of lstm_step_packed_kernel
 };
 // Enqueue all T steps of one bidirectional layer.
 int launch_lstm_layer(const LstmStepArgs &a, hipStream_t st);
@@ -56,7 +57,7 @@ int launch_embed(const float *table, int rows, int E, const int64_t *ids, int B,
                  hipStream_t st);
 // softmax over L of S[b][t][:], ctx = A.V, y = BN(cat(X, ctx)), logits = y.Wfc^T, log-softmax
 int launch_attn_tail(const float *S, int Lp, const float *X, const float *V, const float *fscale, const float *fshift,
-                     const float *wfc, float *logp, int Tp, int B, int L, int H2, int C, hipStream_t st);
+                     const float *wfc, const float *wfcp, float *logp, int Tp, int B, int L, int H2, int C, hipStream_t st);
 
 int init_kernel_attributes();
 
