@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_HERE, "libmdd_hip.so")
 
 EXPORTS = (
     "mdd_last_error", "mdd_version", "mdd_create", "mdd_destroy", "mdd_load_weight", "mdd_finalize_weights",
-    "mdd_stack_len", "mdd_stack_skip", "mdd_len_frames", "mdd_forward", "mdd_forward_num_stages", "mdd_forward_profile", "mdd_tap", "mdd_tap_copy", "mdd_enable_taps", "mdd_sync",
+    "mdd_set_precision", "mdd_get_precision", "mdd_stack_len", "mdd_stack_skip", "mdd_len_frames", "mdd_forward", "mdd_forward_num_stages", "mdd_forward_profile", "mdd_tap", "mdd_tap_copy", "mdd_enable_taps", "mdd_sync",
     "mdd_greedy", "mdd_beam", "mdd_ctc_loss", "mdd_align",
 )
 
@@ -48,6 +48,8 @@ def lib():
     L.mdd_destroy.restype = None
     L.mdd_load_weight.argtypes = [vp, C.c_char_p, vp, i64p, i32]
     L.mdd_finalize_weights.argtypes = [vp]
+    L.mdd_set_precision.argtypes = [vp, i32]
+    L.mdd_get_precision.argtypes = [vp]
     L.mdd_stack_len.argtypes = [i32, i32, i32]
     L.mdd_stack_len.restype = i32
     L.mdd_stack_skip.argtypes = [vp, i32, i32, i32, i32, i32, i32, vp, vp]

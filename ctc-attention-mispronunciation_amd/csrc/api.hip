@@ -35,6 +35,7 @@ struct mdd_model {
     mdd_config cfg;
     int device = 0;
     bool finalized = false, taps = false, use_graph = true;
+    int precision = 1;   // 0: exact fp32 MFMA everywhere, 1: split-bf16 x3 for the time-batched GEMMs (when the geometry allows)
     std::map<std::string, std::vector<float>> host;  // state_dict entries as loaded
     // device weights
     float *w_conv0 = nullptr, *sc0 = nullptr, *sh0 = nullptr;
@@ -42,9 +43,12 @@ struct mdd_model {
     std::vector<float *> wih, whh, bn_scale, bn_shift;  // per rnn layer (bn_* of layer n applies to layer n's INPUT)
     float *emb = nullptr, *t_wih = nullptr, *t_whh = nullptr, *t_bias = nullptr;
     float *w_score = nullptr, *fscale = nullptr, *fshift = nullptr, *w_fc = nullptr, *w_fcp = nullptr;
+    std::vector<mdd::SplitPtr> wih_s;                       // split-bf16 copies of the GEMM weights
+    mdd::SplitPtr t_wih_s{nullptr, nullptr}, w_score_s{nullptr, nullptr};
     std::vector<void *> owned;  // every hipMalloc'd weight pointer
     // workspace
     mdd::DevBuf y0, seq0, gx, act[2], xraw, hbuf, cbuf, embo, text, key, S;
+    mdd::DevBuf seq0_s, act_s[2], x_s, embo_s, text_s, key_s;   // split-bf16 activations (hi plane, then lo plane)
     std::vector<mdd::DevBuf> tap_rnn;
     int *err_flag = nullptr;
     hipStream_t cap_stream = nullptr;  // graphs are captured here (the legacy default stream cannot capture)
@@ -53,6 +57,9 @@ struct mdd_model {
     int W1() const { return (cfg.feat + 2 - 3) / 2 + 1; }
     int W2() const { return (W1() + 2 - 3) / 2 + 1; }
     int rnn_in() const { return cfg.channels * W2(); }
+    bool x3() const {   // the bf16x3 GEMM needs K % 32 == 0 for every contraction and the packed LSTM layouts
+        return precision == 1 && (cfg.hidden == 384 || cfg.hidden == 256) && rnn_in() % 32 == 0 && cfg.emb_dim % 32 == 0;
+    }
 };
 
 namespace mdd {
@@ -63,6 +70,34 @@ static int upload(mdd_model *m, const std::vector<float> &h, float **dev) {
     MDD_HIP_CHECK(hipMemcpy(*dev, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice));
     return MDD_OK;
 }
+
+static unsigned short host_bf16(float x) {   // round-to-nearest-even (weights are finite)
+    unsigned u; memcpy(&u, &x, 4);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+static float host_bf16_f32(unsigned short b) { unsigned u = (unsigned)b << 16; float f; memcpy(&f, &u, 4); return f; }
+
+static int upload_split(mdd_model *m, const std::vector<float> &h, SplitPtr *out) {
+    const size_t n = h.size();
+    std::vector<unsigned short> buf(2 * n);
+    for (size_t i = 0; i < n; i++) {
+        buf[i] = host_bf16(h[i]);
+        buf[n + i] = host_bf16(h[i] - host_bf16_f32(buf[i]));
+    }
+    unsigned short *d = nullptr;
+    MDD_HIP_CHECK(hipMalloc((void **)&d, 2 * n * sizeof(unsigned short)));
+    m->owned.push_back(d);
+    MDD_HIP_CHECK(hipMemcpy(d, buf.data(), 2 * n * sizeof(unsigned short), hipMemcpyHostToDevice));
+    out->hi = d; out->lo = d + n;
+    return MDD_OK;
+}
+
+// a DevBuf of n floats holds a split tensor of n elements: hi plane then lo plane
+static SplitPtr split_view(const DevBuf &b, size_t n) {
+    SplitPtr s; s.hi = reinterpret_cast<unsigned short *>(b.p); s.lo = s.hi ? s.hi + n : nullptr; return s;
+}
+static const SplitPtr kNoSplit = {nullptr, nullptr};
 
 static bool g_ws_moved = false;  // a workspace buffer was reallocated: captured graphs hold stale pointers
 
@@ -138,21 +173,28 @@ static int run_stage(mdd_model *m, int si, const float *x, int B, int T, const i
                      hipStream_t st, Stage *info) {
     const mdd_config &c = m->cfg;
     const int H = c.hidden, H2 = 2 * H, G2 = 8 * H, Tp = T / 2, Lp = L, nl = c.layers;
+    const bool x3 = m->x3();
+    const size_t rows = (size_t)Tp * B, trows = (size_t)L * B;
     static thread_local char namebuf[32];
     Stage dummy; if (!info) info = &dummy;
     info->launches = 1; info->flops = 0.0;
     if (si == 0) { info->name = "conv0"; info->flops = 2.0 * 9 * c.channels * (double)B * T * m->W1();
         return launch_conv0(x, m->w_conv0, m->sc0, m->sh0, m->y0.p, B, T, c.feat, c.channels, st); }
     if (si == 1) { info->name = "conv1"; info->flops = 2.0 * 9 * c.channels * c.channels * (double)B * Tp * m->W2();
-        return launch_conv1(m->y0.p, m->w_conv1t, m->sc1, m->sh1, m->seq0.p, B, T, m->W1(), c.channels, st); }
+        return launch_conv1(m->y0.p, m->w_conv1t, m->sc1, m->sh1, x3 ? nullptr : m->seq0.p,
+                            x3 ? split_view(m->seq0_s, rows * m->rnn_in()) : kNoSplit, B, T, m->W1(), c.channels, st); }
     si -= 2;
     if (si < 2 * nl) {
         const int n = si / 2;
-        const float *in = n == 0 ? m->seq0.p : m->act[(n - 1) & 1].p;
         const int K = n == 0 ? m->rnn_in() : H2;
         if (si % 2 == 0) {
             snprintf(namebuf, sizeof(namebuf), "gemm_ih%d", n); info->name = namebuf;
             info->flops = 2.0 * (double)Tp * B * G2 * K;
+            if (x3) {
+                const SplitPtr in = n == 0 ? split_view(m->seq0_s, rows * K) : split_view(m->act_s[(n - 1) & 1], rows * K);
+                return launch_gemm_bf16x3(in, m->wih_s[n], nullptr, m->gx.p, nullptr, Tp * B, G2, K, K, K, G2, 1, 0, 0, 0, st);
+            }
+            const float *in = n == 0 ? m->seq0.p : m->act[(n - 1) & 1].p;
             return launch_gemm_nt(in, m->wih[n], nullptr, m->gx.p, Tp * B, G2, K, K, K, G2, 1, 0, 0, 0, st);
         }
         snprintf(namebuf, sizeof(namebuf), "lstm%d", n); info->name = namebuf;
@@ -160,9 +202,12 @@ static int run_stage(mdd_model *m, int si, const float *x, int B, int T, const i
         LstmStepArgs a;
         a.gx = m->gx.p; a.whh = m->whh[n]; a.hbuf = m->hbuf.p; a.cbuf = m->cbuf.p;
         a.T = Tp; a.B = B; a.H = H; a.packed = use_packed(m);
-        if (n == nl - 1) { a.out = m->xraw.p; a.out_raw = m->xraw.p; a.oscale = nullptr; a.oshift = nullptr; }
-        else {
-            a.out = m->act[n & 1].p; a.out_raw = m->taps ? m->tap_rnn[n].p : nullptr;
+        if (n == nl - 1) {   // raw h: the attention queries X (fp32 for the tail, split for the score GEMM)
+            a.out = m->xraw.p; a.out_raw = m->xraw.p; a.oscale = nullptr; a.oshift = nullptr;
+            a.out_split = x3 ? split_view(m->x_s, rows * H2) : kNoSplit;
+        } else {             // next layer's BatchNorm folded into the store
+            a.out = x3 ? nullptr : m->act[n & 1].p; a.out_raw = m->taps ? m->tap_rnn[n].p : nullptr;
+            a.out_split = x3 ? split_view(m->act_s[n & 1], rows * H2) : kNoSplit;
             a.oscale = m->bn_scale[n + 1]; a.oshift = m->bn_shift[n + 1];
         }
         return launch_lstm_layer(a, st);
@@ -171,23 +216,34 @@ static int run_stage(mdd_model *m, int si, const float *x, int B, int T, const i
     switch (si) {
     case 0:  // text encoder (model_ctc.py:193,198) and keys (:201)
         info->name = "embed";
-        return launch_embed(m->emb, c.emb_rows, c.emb_dim, x1, B, L, m->embo.p, m->err_flag, st);
+        return launch_embed(m->emb, c.emb_rows, c.emb_dim, x1, B, L, x3 ? nullptr : m->embo.p,
+                            x3 ? split_view(m->embo_s, trows * c.emb_dim) : kNoSplit, m->err_flag, st);
     case 1:
         info->name = "gemm_text"; info->flops = 2.0 * (double)L * B * G2 * c.emb_dim;
+        if (x3) return launch_gemm_bf16x3(split_view(m->embo_s, trows * c.emb_dim), m->t_wih_s, m->t_bias, m->gx.p, nullptr, L * B, G2,
+                                          c.emb_dim, c.emb_dim, c.emb_dim, G2, 1, 0, 0, 0, st);
         return launch_gemm_nt(m->embo.p, m->t_wih, m->t_bias, m->gx.p, L * B, G2, c.emb_dim, c.emb_dim, c.emb_dim, G2, 1, 0, 0, 0, st);
     case 2: {
         info->name = "lstm_text"; info->launches = L; info->flops = 2.0 * 2 * (double)B * H * 4 * H * L;
         LstmStepArgs a;
         a.gx = m->gx.p; a.whh = m->t_whh; a.hbuf = m->hbuf.p; a.cbuf = m->cbuf.p;
         a.out = m->text.p; a.out_raw = m->text.p; a.oscale = nullptr; a.oshift = nullptr;
+        a.out_split = x3 ? split_view(m->text_s, trows * H2) : kNoSplit;
         a.T = L; a.B = B; a.H = H; a.packed = use_packed(m);
         return launch_lstm_layer(a, st);
     }
     case 3:
         info->name = "gemm_key"; info->flops = 2.0 * (double)L * B * H2 * H2;
+        if (x3) {
+            const SplitPtr ks = split_view(m->key_s, trows * H2);
+            return launch_gemm_bf16x3(split_view(m->text_s, trows * H2), m->w_score_s, nullptr, nullptr, &ks, L * B, H2, H2, H2, H2, H2,
+                                      1, 0, 0, 0, st);
+        }
         return launch_gemm_nt(m->text.p, m->w_score, nullptr, m->key.p, L * B, H2, H2, H2, H2, H2, 1, 0, 0, 0, st);
     case 4:  // scores S[b][t][l] = X[t,b,:] . key[l,b,:]   (:204)
         info->name = "gemm_score"; info->flops = 2.0 * (double)B * Tp * L * H2;
+        if (x3) return launch_gemm_bf16x3(split_view(m->x_s, rows * H2), split_view(m->key_s, trows * H2), nullptr, m->S.p, nullptr, Tp, L,
+                                          H2, B * H2, B * H2, Lp, B, H2, H2, (long)Tp * Lp, st);
         return launch_gemm_nt(m->xraw.p, m->key.p, nullptr, m->S.p, Tp, L, H2, B * H2, B * H2, Lp, B, H2, H2, (long)Tp * Lp, st);
     default:
         info->name = "attn_tail"; info->flops = 2.0 * (double)B * Tp * ((double)L * H2 + 2.0 * H2 * c.num_class);
@@ -228,6 +284,8 @@ extern "C" int mdd_create(const mdd_config *cfg, int device, mdd_model **out) {
     mdd_model *m = new mdd_model();
     m->cfg = *cfg;
     m->device = device;
+    const char *pr = getenv("MDD_PRECISION");
+    if (pr && (!strcmp(pr, "f32") || !strcmp(pr, "0"))) m->precision = 0;
     const char *g = getenv("MDD_GRAPH");
     m->use_graph = !(g && g[0] == '0');
     if (int rc = init_kernel_attributes()) { delete m; return rc; }
@@ -245,7 +303,8 @@ extern "C" void mdd_destroy(mdd_model *m) {
     (void)hipDeviceSynchronize();
     for (auto &kv : m->graphs) (void)hipGraphExecDestroy(kv.second);
     for (void *p : m->owned) (void)hipFree(p);
-    DevBuf *bufs[] = {&m->y0, &m->seq0, &m->gx, &m->act[0], &m->act[1], &m->xraw, &m->hbuf, &m->cbuf, &m->embo, &m->text, &m->key, &m->S};
+    DevBuf *bufs[] = {&m->y0, &m->seq0, &m->gx, &m->act[0], &m->act[1], &m->xraw, &m->hbuf, &m->cbuf, &m->embo, &m->text, &m->key, &m->S,
+                      &m->seq0_s, &m->act_s[0], &m->act_s[1], &m->x_s, &m->embo_s, &m->text_s, &m->key_s};
     for (DevBuf *b : bufs) if (b->p) (void)hipFree(b->p);
     for (auto &b : m->tap_rnn) if (b.p) (void)hipFree(b.p);
     if (m->err_flag) (void)hipFree(m->err_flag);
@@ -271,7 +330,7 @@ extern "C" int mdd_finalize_weights(mdd_model *m) {
     const int ch = c.channels, H = c.hidden;
     int rc;
     for (void *p : m->owned) (void)hipFree(p);
-    m->owned.clear(); m->wih.clear(); m->whh.clear();
+    m->owned.clear(); m->wih.clear(); m->whh.clear(); m->wih_s.clear();
     m->bn_scale.assign(c.layers, nullptr); m->bn_shift.assign(c.layers, nullptr);
     for (auto &kv : m->graphs) (void)hipGraphExecDestroy(kv.second);
     m->graphs.clear();
@@ -299,6 +358,7 @@ extern "C" int mdd_finalize_weights(mdd_model *m) {
         if (!pack_gate_rows(m, base, "weight_ih_l0", H, K, tmp)) return MDD_ERR_STATE;
         if ((rc = upload(m, tmp, &d))) return rc;
         m->wih.push_back(d);
+        { SplitPtr sp{nullptr, nullptr}; if ((rc = upload_split(m, tmp, &sp))) return rc; m->wih_s.push_back(sp); }
         if (!pack_gate_rows(m, base, "weight_hh_l0", H, H, tmp)) return MDD_ERR_STATE;
         if (use_packed(m)) { std::vector<float> pk; pack_whh(tmp, H, pk); tmp.swap(pk); }
         if ((rc = upload(m, tmp, &d))) return rc;
@@ -314,7 +374,7 @@ extern "C" int mdd_finalize_weights(mdd_model *m) {
         if (!e) return MDD_ERR_STATE;
         if ((rc = upload(m, *e, &m->emb))) return rc;
         if (!pack_gate_rows(m, "lstm_embeds.", "weight_ih_l0", H, c.emb_dim, tmp)) return MDD_ERR_STATE;
-        if ((rc = upload(m, tmp, &m->t_wih))) return rc;
+        if ((rc = upload(m, tmp, &m->t_wih)) || (rc = upload_split(m, tmp, &m->t_wih_s))) return rc;
         if (!pack_gate_rows(m, "lstm_embeds.", "weight_hh_l0", H, H, tmp)) return MDD_ERR_STATE;
         if (use_packed(m)) { std::vector<float> pk; pack_whh(tmp, H, pk); tmp.swap(pk); }
         if ((rc = upload(m, tmp, &m->t_whh))) return rc;
@@ -327,6 +387,7 @@ extern "C" int mdd_finalize_weights(mdd_model *m) {
         const auto *ws = get(m, "score.weight", (size_t)4 * H * H), *wf = get(m, "fc.1.weight", (size_t)c.num_class * 4 * H);
         if (!ws || !wf) return MDD_ERR_STATE;
         if (!bn_fold(m, "fc.0", 4 * H, sc, sh)) return MDD_ERR_STATE;
+        if ((rc = upload_split(m, *ws, &m->w_score_s))) return rc;
         if ((rc = upload(m, *ws, &m->w_score)) || (rc = upload(m, *wf, &m->w_fc)) || (rc = upload(m, sc, &m->fscale)) ||
             (rc = upload(m, sh, &m->fshift))) return rc;
         m->w_fcp = nullptr;
@@ -357,6 +418,17 @@ extern "C" int mdd_enable_taps(mdd_model *m, int32_t on) {
     m->graphs.clear();
     return MDD_OK;
 }
+
+extern "C" int mdd_set_precision(mdd_model *m, int32_t mode) {
+    if (!m || (mode != 0 && mode != 1)) { set_error("mdd_set_precision: mode must be 0 (fp32 MFMA) or 1 (split-bf16 x3)"); return MDD_ERR_ARG; }
+    if (m->precision != mode) {
+        m->precision = mode;
+        for (auto &kv : m->graphs) (void)hipGraphExecDestroy(kv.second);
+        m->graphs.clear();
+    }
+    return MDD_OK;
+}
+extern "C" int32_t mdd_get_precision(mdd_model *m) { return m ? (m->x3() ? 1 : 0) : -1; }
 
 extern "C" int32_t mdd_stack_len(int32_t T_raw, int32_t skip, int32_t n_down) {
     int kept = (skip <= 1) ? T_raw : (T_raw + skip - 1) / skip;
@@ -392,6 +464,11 @@ static int forward_prepare(mdd_model *m, const float *x_dev, int32_t B, int32_t 
         (rc = ensure(m->xraw, rows * 2 * H)) || (rc = ensure(m->hbuf, (size_t)4 * ((B + 15) / 16 * 16) * H)) || (rc = ensure(m->cbuf, (size_t)2 * ((B + 15) / 16 * 16) * H)) ||
         (rc = ensure(m->embo, trows * c.emb_dim)) || (rc = ensure(m->text, trows * 2 * H)) || (rc = ensure(m->key, trows * 2 * H)) ||
         (rc = ensure(m->S, (size_t)B * Tp * L)))
+        return rc;
+    if (m->x3() && ((rc = ensure(m->seq0_s, rows * m->rnn_in())) || (rc = ensure(m->act_s[0], rows * 2 * H)) ||
+                    (rc = ensure(m->act_s[1], rows * 2 * H)) || (rc = ensure(m->x_s, rows * 2 * H)) ||
+                    (rc = ensure(m->embo_s, trows * c.emb_dim)) || (rc = ensure(m->text_s, trows * 2 * H)) ||
+                    (rc = ensure(m->key_s, trows * 2 * H))))
         return rc;
     if (m->taps) {
         m->tap_rnn.resize(c.layers);
@@ -483,7 +560,15 @@ extern "C" const float *mdd_tap(mdd_model *m, const char *name, int64_t *numel) 
     std::string n(name);
     const float *p = nullptr;
     int64_t ne = 0;
-    if (n == "conv1") { p = m->seq0.p; ne = (int64_t)Tp * B * m->rnn_in(); }
+    if (m->x3() && (n == "conv1" || n == "key")) {   // these stages exist only as split-bf16 planes: rebuild fp32 = hi + lo
+        const bool cv = n == "conv1";
+        ne = cv ? (int64_t)Tp * B * m->rnn_in() : (int64_t)L * B * H2;
+        DevBuf &dst = cv ? m->seq0 : m->key;
+        if (launch_unsplit(split_view(cv ? m->seq0_s : m->key_s, (size_t)ne), (size_t)ne, dst.p, nullptr) != MDD_OK) return nullptr;
+        if (hipStreamSynchronize(nullptr) != hipSuccess) return nullptr;
+        p = dst.p;
+    }
+    else if (n == "conv1") { p = m->seq0.p; ne = (int64_t)Tp * B * m->rnn_in(); }
     else if (n == "text") { p = m->text.p; ne = (int64_t)L * B * H2; }
     else if (n == "key") { p = m->key.p; ne = (int64_t)L * B * H2; }
     else if (n.compare(0, 3, "rnn") == 0) {

@@ -12,7 +12,8 @@
 namespace mdd {
 
 __global__ void embed_kernel(const float *__restrict__ table, int rows, int E, const int64_t *__restrict__ ids, int B,
-                             int L, float *__restrict__ out, int *err_flag) {
+                             int L, float *__restrict__ out, unsigned short *__restrict__ out_hi,
+                             unsigned short *__restrict__ out_lo, int *err_flag) {
     // out row m = l*B + b  (time-major, like every other sequence buffer)
     const int m = blockIdx.x, l = m / B, b = m - l * B;
     long id = ids[(size_t)b * L + l];
@@ -21,13 +22,20 @@ __global__ void embed_kernel(const float *__restrict__ table, int rows, int E, c
         id = 0;
     }
     const float *src = table + (size_t)id * E;
-    float *dst = out + (size_t)m * E;
-    for (int e = threadIdx.x; e < E; e += blockDim.x) dst[e] = src[e];
+    for (int e = threadIdx.x; e < E; e += blockDim.x) {
+        const float v = src[e];
+        if (out) out[(size_t)m * E + e] = v;
+        if (out_hi) {
+            __bf16 h = (__bf16)v, l = (__bf16)(v - (float)h);
+            out_hi[(size_t)m * E + e] = *reinterpret_cast<unsigned short *>(&h);
+            out_lo[(size_t)m * E + e] = *reinterpret_cast<unsigned short *>(&l);
+        }
+    }
 }
 
-int launch_embed(const float *table, int rows, int E, const int64_t *ids, int B, int L, float *out, int *err_flag,
-                 hipStream_t st) {
-    hipLaunchKernelGGL(embed_kernel, dim3(B * L), dim3(128), 0, st, table, rows, E, ids, B, L, out, err_flag);
+int launch_embed(const float *table, int rows, int E, const int64_t *ids, int B, int L, float *out, SplitPtr sp,
+                 int *err_flag, hipStream_t st) {
+    hipLaunchKernelGGL(embed_kernel, dim3(B * L), dim3(128), 0, st, table, rows, E, ids, B, L, out, sp.hi, sp.lo, err_flag);
     MDD_LAUNCH_CHECK();
     return MDD_OK;
 }

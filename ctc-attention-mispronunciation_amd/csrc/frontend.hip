@@ -90,7 +90,8 @@ int launch_conv0(const float *x, const float *w, const float *scale, const float
 template <int CH>
 __global__ __launch_bounds__(256) void conv1_kernel(const float *__restrict__ y0, const float *__restrict__ w_t,
                                                     const float *__restrict__ scale, const float *__restrict__ shift,
-                                                    float *__restrict__ seq, int B, int T, int W1, int W2) {
+                                                    float *__restrict__ seq, unsigned short *__restrict__ seq_hi,
+                                                    unsigned short *__restrict__ seq_lo, int B, int T, int W1, int W2) {
     __shared__ __attribute__((aligned(16))) float wl[CH * 9 * CH];
     for (int i = threadIdx.x; i < CH * 9 * CH; i += blockDim.x) wl[i] = w_t[i];
     __syncthreads();
@@ -127,25 +128,30 @@ __global__ __launch_bounds__(256) void conv1_kernel(const float *__restrict__ y0
             }
         }
     }
-    float *o = seq + ((size_t)tp * B + b) * CH * W2;
+    const size_t ob = ((size_t)tp * B + b) * CH * W2;
 #pragma unroll
     for (int c = 0; c < CH; c++) {
         float v0 = acc0[c] * scale[c] + shift[c];
-        o[c * W2 + wo] = v0 > 0.f ? v0 : 0.f;
-        if (wo + 1 < W2) {
-            float v1 = acc1[c] * scale[c] + shift[c];
-            o[c * W2 + wo + 1] = v1 > 0.f ? v1 : 0.f;
+        float v1 = acc1[c] * scale[c] + shift[c];
+        v0 = v0 > 0.f ? v0 : 0.f; v1 = v1 > 0.f ? v1 : 0.f;
+        const size_t o = ob + c * W2 + wo;
+        if (seq) { seq[o] = v0; if (wo + 1 < W2) seq[o + 1] = v1; }
+        if (seq_hi) {   // split-bf16 planes for the bf16x3 input projection
+            __bf16 h0 = (__bf16)v0, h1 = (__bf16)v1;
+            __bf16 l0 = (__bf16)(v0 - (float)h0), l1 = (__bf16)(v1 - (float)h1);
+            seq_hi[o] = *reinterpret_cast<unsigned short *>(&h0); seq_lo[o] = *reinterpret_cast<unsigned short *>(&l0);
+            if (wo + 1 < W2) { seq_hi[o + 1] = *reinterpret_cast<unsigned short *>(&h1); seq_lo[o + 1] = *reinterpret_cast<unsigned short *>(&l1); }
         }
     }
 }
 
-int launch_conv1(const float *y0, const float *w_t, const float *scale, const float *shift, float *seq, int B, int T,
-                 int W1, int ch, hipStream_t st) {
+int launch_conv1(const float *y0, const float *w_t, const float *scale, const float *shift, float *seq, SplitPtr sp, int B,
+                 int T, int W1, int ch, hipStream_t st) {
     int W2 = (W1 + 2 - 3) / 2 + 1;
     int pairs = (W2 + 1) / 2;
     dim3 grid(((T / 2) * pairs + 255) / 256, 1, B), block(256);
-    if (ch == 32) hipLaunchKernelGGL(conv1_kernel<32>, grid, block, 0, st, y0, w_t, scale, shift, seq, B, T, W1, W2);
-    else if (ch == 4) hipLaunchKernelGGL(conv1_kernel<4>, grid, block, 0, st, y0, w_t, scale, shift, seq, B, T, W1, W2);
+    if (ch == 32) hipLaunchKernelGGL(conv1_kernel<32>, grid, block, 0, st, y0, w_t, scale, shift, seq, sp.hi, sp.lo, B, T, W1, W2);
+    else if (ch == 4) hipLaunchKernelGGL(conv1_kernel<4>, grid, block, 0, st, y0, w_t, scale, shift, seq, sp.hi, sp.lo, B, T, W1, W2);
     else { set_error("conv1: channels=%d not built (32 or 4)", ch); return MDD_ERR_ARG; }
     MDD_LAUNCH_CHECK();
     return MDD_OK;

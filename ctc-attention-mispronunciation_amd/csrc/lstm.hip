@@ -70,7 +70,13 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(LstmStepArgs a, int s) {
         hnext[(size_t)b * H + u] = hn;
         const size_t oi = ((size_t)t * B + b) * 2 * H + d * H + u;
         if (a.out_raw) a.out_raw[oi] = hn;
-        if (a.out != a.out_raw) a.out[oi] = a.oscale ? hn * a.oscale[d * H + u] + a.oshift[d * H + u] : hn;
+        const float ov = a.oscale ? hn * a.oscale[d * H + u] + a.oshift[d * H + u] : hn;
+        if (a.out && a.out != a.out_raw) a.out[oi] = ov;
+        if (a.out_split.hi) {
+            __bf16 hb = (__bf16)ov, lb = (__bf16)(ov - (float)hb);
+            a.out_split.hi[oi] = *reinterpret_cast<unsigned short *>(&hb);
+            a.out_split.lo[oi] = *reinterpret_cast<unsigned short *>(&lb);
+        }
     }
 }
 
@@ -133,7 +139,13 @@ __global__ __launch_bounds__(256, 1) void lstm_step_packed_kernel(LstmStepArgs a
         hnext[(((size_t)(d * NBT + bt) * J + (ut >> 2)) * 64 + (ut & 3) * 16 + li) * 4 + uu] = hn;
         const size_t oi = ((size_t)t * B + b) * 2 * H + d * H + u;
         if (a.out_raw) a.out_raw[oi] = hn;
-        if (a.out != a.out_raw) a.out[oi] = a.oscale ? hn * a.oscale[d * H + u] + a.oshift[d * H + u] : hn;
+        const float ov = a.oscale ? hn * a.oscale[d * H + u] + a.oshift[d * H + u] : hn;
+        if (a.out && a.out != a.out_raw) a.out[oi] = ov;
+        if (a.out_split.hi) {
+            __bf16 hb = (__bf16)ov, lb = (__bf16)(ov - (float)hb);
+            a.out_split.hi[oi] = *reinterpret_cast<unsigned short *>(&hb);
+            a.out_split.lo[oi] = *reinterpret_cast<unsigned short *>(&lb);
+        }
     }
 }
 

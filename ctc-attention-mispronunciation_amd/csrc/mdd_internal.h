@@ -24,26 +24,37 @@ void set_error(const char *fmt, ...);
 
 #define MDD_LAUNCH_CHECK() MDD_HIP_CHECK(hipGetLastError())
 
+// A split-bf16 tensor: hi = bf16(x), lo = bf16(x - hi), two planes of the same [rows][ld] shape.
+struct SplitPtr { unsigned short *hi, *lo; };
+
 // ---- kernel launchers (each enqueues on `st`, returns an mdd_status) -------------------------
 // C[M,N] = A[M,K] . W[N,K]^T (+ bias[N]); fp32 MFMA (v_mfma_f32_32x32x2_f32).  Batched over
 // `batch` with element strides sA/sW/sC.
 int launch_gemm_nt(const float *A, const float *W, const float *bias, float *C, int M, int N, int K, int lda, int ldw,
                    int ldc, int batch, long sA, long sW, long sC, hipStream_t st);
 
+// C = A . W^T on the bf16 matrix cores with split-bf16 operands (see gemm_bf16x3.hip).  Output fp32 C, or a
+// split-bf16 tensor when Csplit != nullptr.  K % 32 == 0, ld* % 8 == 0.
+int launch_gemm_bf16x3(const SplitPtr &A, const SplitPtr &W, const float *bias, float *C, const SplitPtr *Csplit, int M, int N,
+                       int K, int lda, int ldw, int ldc, int batch, long sA, long sW, long sC, hipStream_t st);
+int launch_split(const float *x, size_t n, const SplitPtr &out, hipStream_t st);
+int launch_unsplit(const SplitPtr &in, size_t n, float *x, hipStream_t st);
+
 int launch_stack_skip(const float *raw, int B, int T_raw, int D, int right, int skip, int n_down, float *out,
                       hipStream_t st);
 // conv0: x [B,T,F] -> y0 [B,ch,T,W1]; conv1: y0 -> seq [T/2,B,ch*W2] (BN+ReLU folded; scale/shift per channel)
 int launch_conv0(const float *x, const float *w, const float *scale, const float *shift, float *y0, int B, int T, int F,
                  int ch, hipStream_t st);
-int launch_conv1(const float *y0, const float *w_t, const float *scale, const float *shift, float *seq, int B, int T,
-                 int W1, int ch, hipStream_t st);
+int launch_conv1(const float *y0, const float *w_t, const float *scale, const float *shift, float *seq, SplitPtr seq_split, int B,
+                 int T, int W1, int ch, hipStream_t st);  // seq (fp32) and/or seq_split may be null
 
 struct LstmStepArgs {
     const float *gx;     // [T][B][2][4H], gate columns permuted to u*4+g
     const float *whh;    // [2][4H][H], rows permuted the same way
     float *hbuf;         // [2 parity][2 dir][B][H]
     float *cbuf;         // [2 dir][B][H]
-    float *out;          // [T][B][2H] layer output with oscale/oshift applied (may equal out_raw)
+    float *out;          // [T][B][2H] layer output with oscale/oshift applied (may equal out_raw; nullable)
+    SplitPtr out_split;  // same values as split-bf16 planes (nullable): the next GEMM's A operand
     float *out_raw;      // [T][B][2H] raw h (nullable)
     const float *oscale; // [2H] (nullable -> identity)
     const float *oshift;
@@ -53,8 +64,8 @@ struct LstmStepArgs {
 // Enqueue all T steps of one bidirectional layer.
 int launch_lstm_layer(const LstmStepArgs &a, hipStream_t st);
 
-int launch_embed(const float *table, int rows, int E, const int64_t *ids, int B, int L, float *out, int *err_flag,
-                 hipStream_t st);
+int launch_embed(const float *table, int rows, int E, const int64_t *ids, int B, int L, float *out, SplitPtr out_split,
+                 int *err_flag, hipStream_t st);
 // softmax over L of S[b][t][:], ctx = A.V, y = BN(cat(X, ctx)), logits = y.Wfc^T, log-softmax
 int launch_attn_tail(const float *S, int Lp, const float *X, const float *V, const float *fscale, const float *fshift,
                      const float *wfc, const float *wfcp, float *logp, int Tp, int B, int L, int H2, int C, hipStream_t st);

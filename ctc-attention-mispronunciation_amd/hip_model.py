@@ -10,7 +10,7 @@ from . import _lib
 
 
 class HipModel(object):
-    def __init__(self, geom, state_dict, device=0, taps=False):
+    def __init__(self, geom, state_dict, device=0, taps=False, precision=None):
         _lib.require_gpu()
         self.geom = geom
         self.device = torch.device("cuda", device)
@@ -18,9 +18,15 @@ class HipModel(object):
         cfg = _lib.MddConfig(feat=geom.feat, hidden=geom.hidden, layers=geom.layers, num_class=geom.num_class,
                              channels=geom.channels, emb_rows=geom.emb_rows, emb_dim=geom.emb_dim, bn_eps=1e-5)
         _lib.check(_lib.lib().mdd_create(C.byref(cfg), device, C.byref(self.handle)))
+        if precision is not None:      # 'f32' (exact fp32 MFMA) or 'bf16x3' (split-bf16, default)
+            _lib.check(_lib.lib().mdd_set_precision(self.handle, {'f32': 0, 'bf16x3': 1}[precision]))
         self.load_state_dict(state_dict)
         if taps:
             _lib.check(_lib.lib().mdd_enable_taps(self.handle, 1))
+
+    @property
+    def precision(self):
+        return {0: 'f32', 1: 'bf16x3'}[_lib.lib().mdd_get_precision(self.handle)]
 
     def load_state_dict(self, state_dict):
         L = _lib.lib()

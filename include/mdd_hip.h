@@ -67,6 +67,14 @@ int mdd_load_weight(mdd_model *m, const char *key, const float *data, const int6
  * repack LSTM gate rows for the step kernel.  Synchronises the device. */
 int mdd_finalize_weights(mdd_model *m);
 
+/* Arithmetic of the time-batched contractions (BiLSTM input projections, text projection, `score`, attention
+ * scores): 0 = exact fp32 on v_mfma_f32_32x32x2_f32; 1 (default) = split-bf16 "x3" on v_mfma_f32_32x32x16_bf16
+ * (each fp32 operand = bf16 hi + bf16 lo, products hi.hi + hi.lo + lo.hi, fp32 accumulate; measured effect on the
+ * log-probs <= 1e-5, tolerance 1e-4).  Mode 1 falls back to 0 when a contraction length is not a multiple of 32.
+ * Env MDD_PRECISION=f32 selects mode 0 at mdd_create.  mdd_get_precision returns the mode actually in use. */
+int mdd_set_precision(mdd_model *m, int32_t mode);
+int32_t mdd_get_precision(mdd_model *m);
+
 /* ---- A1: make_context(feat,0,right) + skip_feat(.,skip) + pad to a multiple of n_down
  * (AA/utils/tools.py:207-227, AA/utils/data_loader.py:138-142) for B equal-length utterances.
  * raw_dev [B,T_raw,D] -> out_dev [B,T_out,(right+1)*D] with T_out = mdd_stack_len(T_raw,skip,n_down). */

@@ -42,16 +42,28 @@ def test_forward_tiny_every_stage():
     np.testing.assert_allclose(logp, oracle.forward(sd, g["x"], g["x1"]), rtol=0, atol=TOL)
 
 
+@pytest.mark.parametrize("precision", ["f32", "bf16x3"])
 @pytest.mark.parametrize("idx", [0, 1, 2])
-def test_forward_reference_geometry_golden(idx):
+def test_forward_reference_geometry_golden(idx, precision):
     meta = jload("g2_ref.json")[idx]
     ref = npz("g2_ref.npz")[meta["tag"] + "_logp"]
     geom = synth.Geometry(**meta["geom"])
     sd = synth.synth_state_dict(geom, seed=meta["seed"])
     x, x1, _, _ = synth.synth_batch(geom, B=meta["B"], T=meta["T"], L=meta["L"], seed=meta["seed"])
-    m = _hip().HipModel(geom, sd)
+    m = _hip().HipModel(geom, sd, precision=precision, taps=True)
+    assert m.precision == precision
     logp = m.forward(_cuda(x), _cuda(x1)).cpu().numpy()
     np.testing.assert_allclose(logp, ref, rtol=0, atol=TOL)
+    print("%s %s: max|logp - reference| = %.2e" % (meta["tag"], precision, np.abs(logp - ref).max()))
+    # stage taps against the oracle (conv1 / key exist only as split-bf16 planes in bf16x3 mode)
+    taps = {}
+    oracle.forward(sd, x, x1, taps)
+    B, T, L = meta["B"], meta["T"], meta["L"]
+    conv1 = m.tap("conv1").cpu().numpy().reshape(T // 2, B, geom.channels, -1).transpose(1, 2, 0, 3)
+    np.testing.assert_allclose(conv1, taps["conv1"], rtol=0, atol=TOL)
+    for i in range(geom.layers):
+        np.testing.assert_allclose(m.tap("rnn%d" % i).cpu().numpy().reshape(T // 2, B, -1), taps["rnn%d" % i], rtol=0, atol=TOL)
+    np.testing.assert_allclose(m.tap("key").cpu().numpy().reshape(L, B, -1).transpose(1, 0, 2), taps["key"], rtol=0, atol=TOL)
     if meta["min_top2_gap"] > 1e-3:
         assert (logp.argmax(-1) == ref.argmax(-1)).all()
     # graph replay gives the same bits
@@ -87,14 +99,15 @@ def test_dropin_class_matches_golden_and_reference_api():
         model(torch.from_numpy(x), torch.from_numpy(x1))
 
 
-def test_forward_full_size_properties():
+@pytest.mark.parametrize("precision", ["f32", "bf16x3"])
+def test_forward_full_size_properties(precision):
     """BASELINE config size (B=64, 10 s): rows are distributions; an utterance's posteriors do not depend on
     the other utterances of the batch (eval mode has no cross-batch op), bit for bit; and a 2-utterance
     slice agrees with the CPU oracle."""
     geom = synth.Geometry(**synth.REFERENCE)
     sd = synth.synth_state_dict(geom, seed=1234)
     x, x1, _, _ = synth.synth_batch(geom, B=64, T=500, L=40, seed=1234, ragged=True)
-    m = _hip().HipModel(geom, sd)
+    m = _hip().HipModel(geom, sd, precision=precision)
     logp = m.forward(_cuda(x), _cuda(x1))
     assert logp.shape == (250, 64, 45)
     s = torch.exp(logp.double()).sum(-1)
@@ -105,6 +118,7 @@ def test_forward_full_size_properties():
     ref = oracle.forward(sd, x[sub][:, :120], x1[sub])      # bounded slice for the scalar oracle (T=120)
     lp3 = m.forward(_cuda(np.ascontiguousarray(x[sub][:, :120])), _cuda(x1[sub])).cpu().numpy()
     np.testing.assert_allclose(lp3, ref, rtol=0, atol=TOL)
+    print("full-size slice %s: max|logp - oracle| = %.2e" % (precision, np.abs(lp3 - ref).max()))
 
 
 @pytest.mark.parametrize("si", [0, 1])
