@@ -43,12 +43,13 @@ struct mdd_model {
     std::vector<float *> wih, whh, bn_scale, bn_shift;  // per rnn layer (bn_* of layer n applies to layer n's INPUT)
     float *emb = nullptr, *t_wih = nullptr, *t_whh = nullptr, *t_bias = nullptr;
     float *w_score = nullptr, *fscale = nullptr, *fshift = nullptr, *w_fc = nullptr, *w_fcp = nullptr;
-    std::vector<mdd::SplitPtr> wih_s;                       // split-bf16 copies of the GEMM weights
+    std::vector<mdd::SplitPtr> wih_s, whh_s;                // split-bf16 copies of the GEMM / recurrent weights
+    mdd::SplitPtr t_whh_s{nullptr, nullptr};
     mdd::SplitPtr t_wih_s{nullptr, nullptr}, w_score_s{nullptr, nullptr};
     std::vector<void *> owned;  // every hipMalloc'd weight pointer
     // workspace
     mdd::DevBuf y0, seq0, gx, act[2], xraw, hbuf, cbuf, embo, text, key, S;
-    mdd::DevBuf seq0_s, act_s[2], x_s, embo_s, text_s, key_s;   // split-bf16 activations (hi plane, then lo plane)
+    mdd::DevBuf seq0_s, act_s[2], x_s, embo_s, text_s, key_s, hsplit;   // split-bf16 activations (hi plane, then lo plane)
     std::vector<mdd::DevBuf> tap_rnn;
     int *err_flag = nullptr;
     hipStream_t cap_stream = nullptr;  // graphs are captured here (the legacy default stream cannot capture)
@@ -57,6 +58,7 @@ struct mdd_model {
     int W1() const { return (cfg.feat + 2 - 3) / 2 + 1; }
     int W2() const { return (W1() + 2 - 3) / 2 + 1; }
     int rnn_in() const { return cfg.channels * W2(); }
+    bool lstm_x3 = false;   // MDD_LSTM=x3: LDS-tiled split-bf16 step kernel (measured slower than the packed fp32 step; kept for study)
     bool x3() const {   // the bf16x3 GEMM needs K % 32 == 0 for every contraction and the packed LSTM layouts
         return precision == 1 && (cfg.hidden == 384 || cfg.hidden == 256) && rnn_in() % 32 == 0 && cfg.emb_dim % 32 == 0;
     }
@@ -202,6 +204,7 @@ static int run_stage(mdd_model *m, int si, const float *x, int B, int T, const i
         LstmStepArgs a;
         a.gx = m->gx.p; a.whh = m->whh[n]; a.hbuf = m->hbuf.p; a.cbuf = m->cbuf.p;
         a.T = Tp; a.B = B; a.H = H; a.packed = use_packed(m);
+        a.whh_split = m->whh_s[n]; a.hsplit = (x3 && m->lstm_x3) ? reinterpret_cast<unsigned short *>(m->hsplit.p) : nullptr;
         if (n == nl - 1) {   // raw h: the attention queries X (fp32 for the tail, split for the score GEMM)
             a.out = m->xraw.p; a.out_raw = m->xraw.p; a.oscale = nullptr; a.oshift = nullptr;
             a.out_split = x3 ? split_view(m->x_s, rows * H2) : kNoSplit;
@@ -230,6 +233,7 @@ static int run_stage(mdd_model *m, int si, const float *x, int B, int T, const i
         a.out = m->text.p; a.out_raw = m->text.p; a.oscale = nullptr; a.oshift = nullptr;
         a.out_split = x3 ? split_view(m->text_s, trows * H2) : kNoSplit;
         a.T = L; a.B = B; a.H = H; a.packed = use_packed(m);
+        a.whh_split = m->t_whh_s; a.hsplit = (x3 && m->lstm_x3) ? reinterpret_cast<unsigned short *>(m->hsplit.p) : nullptr;
         return launch_lstm_layer(a, st);
     }
     case 3:
@@ -286,9 +290,12 @@ extern "C" int mdd_create(const mdd_config *cfg, int device, mdd_model **out) {
     m->device = device;
     const char *pr = getenv("MDD_PRECISION");
     if (pr && (!strcmp(pr, "f32") || !strcmp(pr, "0"))) m->precision = 0;
+    const char *lx = getenv("MDD_LSTM");
+    m->lstm_x3 = lx && !strcmp(lx, "x3");
     const char *g = getenv("MDD_GRAPH");
     m->use_graph = !(g && g[0] == '0');
     if (int rc = init_kernel_attributes()) { delete m; return rc; }
+    if (int rc = init_lstm_attributes()) { delete m; return rc; }
     hipError_t e = hipMalloc((void **)&m->err_flag, sizeof(int));
     if (e == hipSuccess) e = hipMemset(m->err_flag, 0, sizeof(int));
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&m->cap_stream, hipStreamNonBlocking);
@@ -304,7 +311,7 @@ extern "C" void mdd_destroy(mdd_model *m) {
     for (auto &kv : m->graphs) (void)hipGraphExecDestroy(kv.second);
     for (void *p : m->owned) (void)hipFree(p);
     DevBuf *bufs[] = {&m->y0, &m->seq0, &m->gx, &m->act[0], &m->act[1], &m->xraw, &m->hbuf, &m->cbuf, &m->embo, &m->text, &m->key, &m->S,
-                      &m->seq0_s, &m->act_s[0], &m->act_s[1], &m->x_s, &m->embo_s, &m->text_s, &m->key_s};
+                      &m->seq0_s, &m->act_s[0], &m->act_s[1], &m->x_s, &m->embo_s, &m->text_s, &m->key_s, &m->hsplit};
     for (DevBuf *b : bufs) if (b->p) (void)hipFree(b->p);
     for (auto &b : m->tap_rnn) if (b.p) (void)hipFree(b.p);
     if (m->err_flag) (void)hipFree(m->err_flag);
@@ -330,7 +337,7 @@ extern "C" int mdd_finalize_weights(mdd_model *m) {
     const int ch = c.channels, H = c.hidden;
     int rc;
     for (void *p : m->owned) (void)hipFree(p);
-    m->owned.clear(); m->wih.clear(); m->whh.clear(); m->wih_s.clear();
+    m->owned.clear(); m->wih.clear(); m->whh.clear(); m->wih_s.clear(); m->whh_s.clear();
     m->bn_scale.assign(c.layers, nullptr); m->bn_shift.assign(c.layers, nullptr);
     for (auto &kv : m->graphs) (void)hipGraphExecDestroy(kv.second);
     m->graphs.clear();
@@ -360,6 +367,7 @@ extern "C" int mdd_finalize_weights(mdd_model *m) {
         m->wih.push_back(d);
         { SplitPtr sp{nullptr, nullptr}; if ((rc = upload_split(m, tmp, &sp))) return rc; m->wih_s.push_back(sp); }
         if (!pack_gate_rows(m, base, "weight_hh_l0", H, H, tmp)) return MDD_ERR_STATE;
+        { SplitPtr sp{nullptr, nullptr}; if ((rc = upload_split(m, tmp, &sp))) return rc; m->whh_s.push_back(sp); }
         if (use_packed(m)) { std::vector<float> pk; pack_whh(tmp, H, pk); tmp.swap(pk); }
         if ((rc = upload(m, tmp, &d))) return rc;
         m->whh.push_back(d);
@@ -376,6 +384,7 @@ extern "C" int mdd_finalize_weights(mdd_model *m) {
         if (!pack_gate_rows(m, "lstm_embeds.", "weight_ih_l0", H, c.emb_dim, tmp)) return MDD_ERR_STATE;
         if ((rc = upload(m, tmp, &m->t_wih)) || (rc = upload_split(m, tmp, &m->t_wih_s))) return rc;
         if (!pack_gate_rows(m, "lstm_embeds.", "weight_hh_l0", H, H, tmp)) return MDD_ERR_STATE;
+        if ((rc = upload_split(m, tmp, &m->t_whh_s))) return rc;
         if (use_packed(m)) { std::vector<float> pk; pack_whh(tmp, H, pk); tmp.swap(pk); }
         if ((rc = upload(m, tmp, &m->t_whh))) return rc;
         std::vector<float> bi, bh;
@@ -468,7 +477,7 @@ static int forward_prepare(mdd_model *m, const float *x_dev, int32_t B, int32_t 
     if (m->x3() && ((rc = ensure(m->seq0_s, rows * m->rnn_in())) || (rc = ensure(m->act_s[0], rows * 2 * H)) ||
                     (rc = ensure(m->act_s[1], rows * 2 * H)) || (rc = ensure(m->x_s, rows * 2 * H)) ||
                     (rc = ensure(m->embo_s, trows * c.emb_dim)) || (rc = ensure(m->text_s, trows * 2 * H)) ||
-                    (rc = ensure(m->key_s, trows * 2 * H))))
+                    (rc = ensure(m->key_s, trows * 2 * H)) || (rc = ensure(m->hsplit, (size_t)4 * B * H))))
         return rc;
     if (m->taps) {
         m->tap_rnn.resize(c.layers);

@@ -149,8 +149,147 @@ __global__ __launch_bounds__(256, 1) void lstm_step_packed_kernel(LstmStepArgs a
     }
 }
 
+// ---- split-bf16 tiled variant: the recurrent product on the bf16 matrix cores, operands shared through LDS.
+// Per step and direction  G^T[4H x B] = Whh'[4H x H] . h^T[H x B]  is a small GEMM that every step re-reads in
+// full, so the step is bound by L2->CU traffic, not by arithmetic.  A workgroup owns RT*16 gate rows (RT*4 hidden
+// units) x 64 batch rows and stages its Whh' panel and its h panel ONCE in LDS (bf16 hi/lo planes: the same 4
+// bytes per element as fp32), instead of every wave streaming both operands from L2 (2.6x less L2 traffic than the
+// packed fp32 variant at B=256).  Products are the bf16x3 form Ah.Bh + Ah.Bl + Al.Bh on v_mfma_f32_16x16x32_bf16
+// (3/16 of the fp32 MFMA time).  The D layout (col = batch, 4 accumulator registers = i,f,g,o of one unit) and the
+// cell epilogue are those of the fp32 variants.  h is exchanged between steps as row-major [dir][B][H] hi/lo planes
+// (the producer lane writes its bf16 pair), c stays fp32 row-major.
+// LDS: Wh | Wl : RT*16 rows, hh | hl : 64 rows, each row H*2 bytes + 16 pad (conflict-free ds_read_b128 fragments).
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+template <int RT, int H>
+__global__ __launch_bounds__(256, 1) void lstm_step_x3_kernel(LstmStepArgs a, int s) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int ROWB = H * 2 + 16, WROWS = RT * 16, CPR = H / 8;   // CPR: 16-byte chunks per row
+    unsigned char *Wh = smem, *Wl = Wh + WROWS * ROWB, *Hh = Wl + WROWS * ROWB, *Hl = Hh + 64 * ROWB;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int d = blockIdx.y, B = a.B;
+    const int r0 = blockIdx.x * WROWS;            // first gate row (permuted order) of this workgroup
+    const int b0 = blockIdx.z * 64;               // first batch row
+    const int t = d ? (a.T - 1 - s) : s;
+    const int li = lane & 15, uu = lane >> 4;
+    const int b = b0 + wave * 16 + li;
+    const size_t hplane = (size_t)2 * B * H;      // elements per (parity, hi|lo) plane: [dir][B][H]
+    const unsigned short *hprev_h = a.hsplit + (size_t)(((s & 1) ^ 1) * 2 + 0) * hplane + (size_t)d * B * H;
+    const unsigned short *hprev_l = a.hsplit + (size_t)(((s & 1) ^ 1) * 2 + 1) * hplane + (size_t)d * B * H;
+
+    f32x4 acc[RT];
+#pragma unroll
+    for (int i = 0; i < RT; i++) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    if (s > 0) {
+        // ---- stage both panels: all loads in flight at once, then one LDS write pass
+        constexpr int WCH = WROWS * CPR, HCH = 64 * CPR;              // chunks per plane
+        static_assert(WCH % 256 == 0 && HCH % 256 == 0, "panel sizes must be whole passes of the workgroup");
+        constexpr int NW = WCH / 256, NH = HCH / 256;
+        u32x4 wvh[NW], wvl[NW], hvh[NH], hvl[NH];
+        const unsigned short *wsrc_h = a.whh_split.hi + ((size_t)d * 4 * H + r0) * H;
+        const unsigned short *wsrc_l = a.whh_split.lo + ((size_t)d * 4 * H + r0) * H;
+        // branch-free: rows past B are clamped to the last valid row (their output columns are never stored)
+#pragma unroll
+        for (int i = 0; i < NW; i++) {
+            const int q = tid + 256 * i;                              // rows are contiguous: chunk q = row q/CPR
+            wvh[i] = *reinterpret_cast<const u32x4 *>(wsrc_h + (size_t)q * 8);
+            wvl[i] = *reinterpret_cast<const u32x4 *>(wsrc_l + (size_t)q * 8);
+        }
+#pragma unroll
+        for (int i = 0; i < NH; i++) {
+            const int q = tid + 256 * i, row = q / CPR, c = q - row * CPR;
+            const int br = min(b0 + row, B - 1);
+            hvh[i] = *reinterpret_cast<const u32x4 *>(hprev_h + (size_t)br * H + c * 8);
+            hvl[i] = *reinterpret_cast<const u32x4 *>(hprev_l + (size_t)br * H + c * 8);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < NW; i++) {
+            const int q = tid + 256 * i, row = q / CPR, c = q - row * CPR;
+            *reinterpret_cast<u32x4 *>(Wh + row * ROWB + c * 16) = wvh[i];
+            *reinterpret_cast<u32x4 *>(Wl + row * ROWB + c * 16) = wvl[i];
+        }
+#pragma unroll
+        for (int i = 0; i < NH; i++) {
+            const int q = tid + 256 * i, row = q / CPR, c = q - row * CPR;
+            *reinterpret_cast<u32x4 *>(Hh + row * ROWB + c * 16) = hvh[i];
+            *reinterpret_cast<u32x4 *>(Hl + row * ROWB + c * 16) = hvl[i];
+        }
+        __syncthreads();
+        // ---- this wave: batch tile `wave` (16 columns) x RT row tiles
+        const unsigned char *hb_h = Hh + (wave * 16 + li) * ROWB + uu * 16;
+        const unsigned char *hb_l = Hl + (wave * 16 + li) * ROWB + uu * 16;
+#pragma unroll 4
+        for (int ks = 0; ks < H / 32; ks++) {
+            const bf16x8 bh = *reinterpret_cast<const bf16x8 *>(hb_h + ks * 64);
+            const bf16x8 bl = *reinterpret_cast<const bf16x8 *>(hb_l + ks * 64);
+#pragma unroll
+            for (int rt = 0; rt < RT; rt++) {
+                const bf16x8 ah = *reinterpret_cast<const bf16x8 *>(Wh + (rt * 16 + li) * ROWB + uu * 16 + ks * 64);
+                const bf16x8 al = *reinterpret_cast<const bf16x8 *>(Wl + (rt * 16 + li) * ROWB + uu * 16 + ks * 64);
+                acc[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, acc[rt], 0, 0, 0);
+                acc[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, acc[rt], 0, 0, 0);
+                acc[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, acc[rt], 0, 0, 0);
+            }
+        }
+    }
+    if (b >= B) return;
+    unsigned short *hnext_h = a.hsplit + (size_t)((s & 1) * 2 + 0) * hplane + (size_t)d * B * H;
+    unsigned short *hnext_l = a.hsplit + (size_t)((s & 1) * 2 + 1) * hplane + (size_t)d * B * H;
+#pragma unroll
+    for (int rt = 0; rt < RT; rt++) {
+        const int u = (r0 >> 2) + rt * 4 + uu;    // D: col = lane&15 (batch), row = 4*(lane>>4) + r -> unit uu of the tile, gate r
+        const float4 g4 = *reinterpret_cast<const float4 *>(a.gx + (((size_t)t * B + b) * 2 + d) * 4 * H + u * 4);
+        const size_t ci = ((size_t)d * B + b) * H + u;
+        const float cold = s > 0 ? a.cbuf[ci] : 0.f;
+        const float ig = sigmoid_f(acc[rt][0] + g4.x), fg = sigmoid_f(acc[rt][1] + g4.y);
+        const float cg = tanhf(acc[rt][2] + g4.z), og = sigmoid_f(acc[rt][3] + g4.w);
+        const float cn = fg * cold + ig * cg;
+        const float hn = og * tanhf(cn);
+        a.cbuf[ci] = cn;
+        {
+            __bf16 hb = (__bf16)hn, lb = (__bf16)(hn - (float)hb);
+            hnext_h[(size_t)b * H + u] = *reinterpret_cast<unsigned short *>(&hb);
+            hnext_l[(size_t)b * H + u] = *reinterpret_cast<unsigned short *>(&lb);
+        }
+        const size_t oi = ((size_t)t * B + b) * 2 * H + d * H + u;
+        if (a.out_raw) a.out_raw[oi] = hn;
+        const float ov = a.oscale ? hn * a.oscale[d * H + u] + a.oshift[d * H + u] : hn;
+        if (a.out && a.out != a.out_raw) a.out[oi] = ov;
+        if (a.out_split.hi) {
+            __bf16 hb = (__bf16)ov, lb = (__bf16)(ov - (float)hb);
+            a.out_split.hi[oi] = *reinterpret_cast<unsigned short *>(&hb);
+            a.out_split.lo[oi] = *reinterpret_cast<unsigned short *>(&lb);
+        }
+    }
+}
+
+template <int RT, int H>
+static int launch_x3_steps(const LstmStepArgs &a, hipStream_t st) {
+    constexpr int ROWB = H * 2 + 16;
+    const size_t smem = (size_t)2 * (RT * 16 + 64) * ROWB;
+    dim3 grid(4 * H / (RT * 16), 2, (a.B + 63) / 64), block(256);
+    for (int s = 0; s < a.T; s++) hipLaunchKernelGGL((lstm_step_x3_kernel<RT, H>), grid, block, smem, st, a, s);
+    return MDD_OK;
+}
+
+int init_lstm_attributes() {
+    MDD_HIP_CHECK(hipFuncSetAttribute((const void *)lstm_step_x3_kernel<2, 384>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    MDD_HIP_CHECK(hipFuncSetAttribute((const void *)lstm_step_x3_kernel<2, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    return MDD_OK;
+}
+
 int launch_lstm_layer(const LstmStepArgs &a, hipStream_t st) {
     if (a.H % 4 != 0 || a.T <= 0 || a.B <= 0) { set_error("lstm: bad shape T=%d B=%d H=%d", a.T, a.B, a.H); return MDD_ERR_ARG; }
+    if (a.hsplit) {
+        if (a.H == 384) launch_x3_steps<2, 384>(a, st);
+        else if (a.H == 256) launch_x3_steps<2, 256>(a, st);
+        else { set_error("lstm: split-bf16 step built for H in {256,384}"); return MDD_ERR_ARG; }
+        MDD_LAUNCH_CHECK();
+        return MDD_OK;
+    }
     dim3 grid(a.H / 4, 2, (a.B + 63) / 64), block(256);
     for (int s = 0; s < a.T; s++) {
         if (a.packed && a.H == 384) hipLaunchKernelGGL(lstm_step_packed_kernel<24>, grid, block, 0, st, a, s);

@@ -59,6 +59,8 @@ struct LstmStepArgs {
     const float *oscale; // [2H] (nullable -> identity)
     const float *oshift;
     int T, B, H;
+    SplitPtr whh_split;  // row-major Whh' [2][4H][H] as hi/lo planes (split-bf16 step only)
+    unsigned short *hsplit;  // h exchange of the split-bf16 step: [2 parity][hi|lo][2 dir][B][H]; null selects the fp32 steps
     int packed;          // 1: whh / hbuf / cbuf use the packed consumer layouts of lstm_step_packed_kernel
 };
 // Enqueue all T steps of one bidirectional layer.
@@ -71,5 +73,6 @@ int launch_attn_tail(const float *S, int Lp, const float *X, const float *V, con
                      const float *wfc, const float *wfcp, float *logp, int Tp, int B, int L, int H2, int C, hipStream_t st);
 
 int init_kernel_attributes();
+int init_lstm_attributes();
 
 }  // namespace mdd
