@@ -115,7 +115,7 @@ def main():
                 x = stack_features(raw, out=self.xbuf)
                 self.model.forward(x, x1, out=self.logp[k])
                 if self.gathered is not None and not args.no_gather:
-                    dist.all_gather_into_tensor(self.gathered[k], self.logp[k])
+                    dist.all_gather_into_tensor(self.gathered[k].view(-1, B, geom.num_class), self.logp[k])
                 self.ev_fwd[k].record(self.s_fwd)
             with torch.cuda.stream(self.s_dec):
                 self.s_dec.wait_event(self.ev_fwd[k])
