@@ -49,7 +49,7 @@ struct mdd_model {
     std::vector<void *> owned;  // every hipMalloc'd weight pointer
     // workspace
     mdd::DevBuf y0, seq0, gx, act[2], xraw, hbuf, cbuf, embo, text, key, S;
-    mdd::DevBuf seq0_s, act_s[2], x_s, embo_s, text_s, key_s, hsplit;   // split-bf16 activations (hi plane, then lo plane)
+    mdd::DevBuf seq0_s, act_s[2], x_s, embo_s, text_s, key_s, hsplit, hx;   // split-bf16 activations (hi plane, then lo plane)
     std::vector<mdd::DevBuf> tap_rnn;
     int *err_flag = nullptr;
     hipStream_t cap_stream = nullptr;  // graphs are captured here (the legacy default stream cannot capture)
@@ -58,7 +58,11 @@ struct mdd_model {
     int W1() const { return (cfg.feat + 2 - 3) / 2 + 1; }
     int W2() const { return (W1() + 2 - 3) / 2 + 1; }
     int rnn_in() const { return cfg.channels * W2(); }
+    bool lstm_persist = true;   // one persistent team-synchronised launch per BiLSTM layer (split-bf16 mode, >= 256 CUs, B <= 512)
+    int n_cu = 0;
+    unsigned int *sync_words = nullptr;
     bool lstm_x3 = false;   // MDD_LSTM=x3: LDS-tiled split-bf16 step kernel (measured slower than the packed fp32 step; kept for study)
+    bool persist(int B) const { return x3() && lstm_persist && !lstm_x3 && n_cu >= 256 && B <= 512; }
     bool x3() const {   // the bf16x3 GEMM needs K % 32 == 0 for every contraction and the packed LSTM layouts
         return precision == 1 && (cfg.hidden == 384 || cfg.hidden == 256) && rnn_in() % 32 == 0 && cfg.emb_dim % 32 == 0;
     }
@@ -213,6 +217,7 @@ static int run_stage(mdd_model *m, int si, const float *x, int B, int T, const i
             a.out_split = x3 ? split_view(m->act_s[n & 1], rows * H2) : kNoSplit;
             a.oscale = m->bn_scale[n + 1]; a.oshift = m->bn_shift[n + 1];
         }
+        if (m->persist(B)) { info->launches = 1; return launch_lstm_layer_persistent(a, reinterpret_cast<unsigned short *>(m->hx.p), m->sync_words, m->err_flag, st); }
         return launch_lstm_layer(a, st);
     }
     si -= 2 * nl;
@@ -234,6 +239,7 @@ static int run_stage(mdd_model *m, int si, const float *x, int B, int T, const i
         a.out_split = x3 ? split_view(m->text_s, trows * H2) : kNoSplit;
         a.T = L; a.B = B; a.H = H; a.packed = use_packed(m);
         a.whh_split = m->t_whh_s; a.hsplit = (x3 && m->lstm_x3) ? reinterpret_cast<unsigned short *>(m->hsplit.p) : nullptr;
+        if (m->persist(B)) { info->launches = 1; return launch_lstm_layer_persistent(a, reinterpret_cast<unsigned short *>(m->hx.p), m->sync_words, m->err_flag, st); }
         return launch_lstm_layer(a, st);
     }
     case 3:
@@ -292,13 +298,17 @@ extern "C" int mdd_create(const mdd_config *cfg, int device, mdd_model **out) {
     if (pr && (!strcmp(pr, "f32") || !strcmp(pr, "0"))) m->precision = 0;
     const char *lx = getenv("MDD_LSTM");
     m->lstm_x3 = lx && !strcmp(lx, "x3");
+    if (lx && !strcmp(lx, "step")) m->lstm_persist = false;
     const char *g = getenv("MDD_GRAPH");
     m->use_graph = !(g && g[0] == '0');
     if (int rc = init_kernel_attributes()) { delete m; return rc; }
     if (int rc = init_lstm_attributes()) { delete m; return rc; }
+    if (int rc = init_persistent_attributes()) { delete m; return rc; }
+    m->n_cu = prop.multiProcessorCount;
     hipError_t e = hipMalloc((void **)&m->err_flag, sizeof(int));
     if (e == hipSuccess) e = hipMemset(m->err_flag, 0, sizeof(int));
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&m->cap_stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipMalloc((void **)&m->sync_words, 32 * sizeof(unsigned int));
     if (e != hipSuccess) { set_error("mdd_create: %s", hipGetErrorString(e)); delete m; return MDD_ERR_HIP; }
     *out = m;
     return MDD_OK;
@@ -311,11 +321,12 @@ extern "C" void mdd_destroy(mdd_model *m) {
     for (auto &kv : m->graphs) (void)hipGraphExecDestroy(kv.second);
     for (void *p : m->owned) (void)hipFree(p);
     DevBuf *bufs[] = {&m->y0, &m->seq0, &m->gx, &m->act[0], &m->act[1], &m->xraw, &m->hbuf, &m->cbuf, &m->embo, &m->text, &m->key, &m->S,
-                      &m->seq0_s, &m->act_s[0], &m->act_s[1], &m->x_s, &m->embo_s, &m->text_s, &m->key_s, &m->hsplit};
+                      &m->seq0_s, &m->act_s[0], &m->act_s[1], &m->x_s, &m->embo_s, &m->text_s, &m->key_s, &m->hsplit, &m->hx};
     for (DevBuf *b : bufs) if (b->p) (void)hipFree(b->p);
     for (auto &b : m->tap_rnn) if (b.p) (void)hipFree(b.p);
     if (m->err_flag) (void)hipFree(m->err_flag);
     if (m->cap_stream) (void)hipStreamDestroy(m->cap_stream);
+    if (m->sync_words) (void)hipFree(m->sync_words);
     delete m;
 }
 
@@ -477,7 +488,8 @@ static int forward_prepare(mdd_model *m, const float *x_dev, int32_t B, int32_t 
     if (m->x3() && ((rc = ensure(m->seq0_s, rows * m->rnn_in())) || (rc = ensure(m->act_s[0], rows * 2 * H)) ||
                     (rc = ensure(m->act_s[1], rows * 2 * H)) || (rc = ensure(m->x_s, rows * 2 * H)) ||
                     (rc = ensure(m->embo_s, trows * c.emb_dim)) || (rc = ensure(m->text_s, trows * 2 * H)) ||
-                    (rc = ensure(m->key_s, trows * 2 * H)) || (rc = ensure(m->hsplit, (size_t)4 * B * H))))
+                    (rc = ensure(m->key_s, trows * 2 * H)) || (rc = ensure(m->hsplit, (size_t)4 * B * H)) ||
+                    (rc = ensure(m->hx, (size_t)2 * 16 * 2 * persistent_bg(B) * H / 2 + 64))))
         return rc;
     if (m->taps) {
         m->tap_rnn.resize(c.layers);
@@ -603,6 +615,11 @@ extern "C" int mdd_sync(mdd_model *m, void *stream) {
     MDD_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
     int flag = 0;
     MDD_HIP_CHECK(hipMemcpy(&flag, m->err_flag, sizeof(int), hipMemcpyDeviceToHost));
+    if (flag == 2) {
+        MDD_HIP_CHECK(hipMemset(m->err_flag, 0, sizeof(int)));
+        set_error("persistent BiLSTM kernel timed out waiting for its team (grid not fully resident?); set MDD_LSTM=step");
+        return MDD_ERR_HIP;
+    }
     if (flag) {
         MDD_HIP_CHECK(hipMemset(m->err_flag, 0, sizeof(int)));
         set_error("index out of range in self");  // the message of the IndexError nn.Embedding raises

@@ -74,5 +74,10 @@ int launch_attn_tail(const float *S, int Lp, const float *X, const float *V, con
 
 int init_kernel_attributes();
 int init_lstm_attributes();
+int init_persistent_attributes();
+// One launch for the whole layer (256 co-resident workgroups, team-synchronised; see lstm.hip).  hx: exchange buffer
+// of 2*16*2*persistent_bg(B)*H ushorts, sync: 32 uints.  Requires B <= 512, H in {256, 384}, >= 256 CUs.
+int persistent_bg(int B);
+int launch_lstm_layer_persistent(const LstmStepArgs &s, unsigned short *hx, unsigned int *sync, int *err_flag, hipStream_t st);
 
 }  // namespace mdd

@@ -219,3 +219,19 @@ def test_stack_skip_golden():
     assert out.shape == (4, 500, 243)
     for b in range(4):
         np.testing.assert_array_equal(out[b], oracle.stack_skip(raw[b]))
+
+
+def test_persistent_lstm_equals_step_kernels_bitwise(monkeypatch):
+    """The persistent team-synchronised layer kernel and the per-step split-bf16 kernel issue the same MFMAs in the
+    same order, so their outputs must be identical bit for bit -- at a fused batch size, full length, with the
+    consumer CUs' caches warm (the hand-off is re-run 3 times)."""
+    geom = synth.Geometry(**synth.REFERENCE)
+    sd = synth.synth_state_dict(geom, seed=1234)
+    x, x1, _, _ = synth.synth_batch(geom, B=160, T=500, L=40, seed=99, ragged=True)
+    monkeypatch.setenv("MDD_LSTM", "x3")
+    ref = _hip().HipModel(geom, sd, precision="bf16x3").forward(_cuda(x), _cuda(x1), sync_errors=True).cpu().numpy()
+    monkeypatch.delenv("MDD_LSTM")
+    m = _hip().HipModel(geom, sd, precision="bf16x3")
+    for _ in range(3):
+        got = m.forward(_cuda(x), _cuda(x1), sync_errors=True).cpu().numpy()
+        np.testing.assert_array_equal(got, ref)
