@@ -489,7 +489,7 @@ static int forward_prepare(mdd_model *m, const float *x_dev, int32_t B, int32_t 
                     (rc = ensure(m->act_s[1], rows * 2 * H)) || (rc = ensure(m->x_s, rows * 2 * H)) ||
                     (rc = ensure(m->embo_s, trows * c.emb_dim)) || (rc = ensure(m->text_s, trows * 2 * H)) ||
                     (rc = ensure(m->key_s, trows * 2 * H)) || (rc = ensure(m->hsplit, (size_t)4 * B * H)) ||
-                    (rc = ensure(m->hx, (size_t)2 * 16 * 2 * persistent_bg(B) * H / 2 + 64))))
+                    (rc = ensure(m->hx, (size_t)2 * 16 * 2 * persistent_bg(B) * H / 2 + 64 + 256 * 6 * 2))))   // + diagnostic stamps
         return rc;
     if (m->taps) {
         m->tap_rnn.resize(c.layers);
@@ -588,6 +588,9 @@ extern "C" const float *mdd_tap(mdd_model *m, const char *name, int64_t *numel) 
         if (launch_unsplit(split_view(cv ? m->seq0_s : m->key_s, (size_t)ne), (size_t)ne, dst.p, nullptr) != MDD_OK) return nullptr;
         if (hipStreamSynchronize(nullptr) != hipSuccess) return nullptr;
         p = dst.p;
+    }
+    else if (n == "lstm_dbg" && m->hx.p) {   // diagnostic stamps of the last persistent layer launch (MDD_LSTM_DBG=1)
+        p = m->hx.p + (size_t)2 * 16 * 2 * persistent_bg(B) * m->cfg.hidden / 2; ne = 256 * 6 * 2;
     }
     else if (n == "conv1") { p = m->seq0.p; ne = (int64_t)Tp * B * m->rnn_in(); }
     else if (n == "text") { p = m->text.p; ne = (int64_t)L * B * H2; }

@@ -23,6 +23,10 @@ namespace mdd {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float sigmoid_f(float v) { return 1.f / (1.f + expf(-v)); }
+// split-bf16 kernels: hardware exp2 / rcp (<= ~2 ulp each; |error| on a gate <= 3e-7, far below the 1e-5 the bf16x3
+// products already spend of the 1e-4 budget).  The exact-fp32 mode keeps the libm-grade functions above.
+__device__ __forceinline__ float fast_sigmoid(float v) { return __builtin_amdgcn_rcpf(1.f + __expf(-v)); }
+__device__ __forceinline__ float fast_tanh(float v) { return 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + __expf(2.f * v)); }
 
 // ---- generic variant (any H % 4 == 0; row-major Whh', h and c): used for small test geometries
 template <bool VEC>
@@ -244,10 +248,10 @@ __global__ __launch_bounds__(256, 1) void lstm_step_x3_kernel(LstmStepArgs a, in
         const float4 g4 = *reinterpret_cast<const float4 *>(a.gx + (((size_t)t * B + b) * 2 + d) * 4 * H + u * 4);
         const size_t ci = ((size_t)d * B + b) * H + u;
         const float cold = s > 0 ? a.cbuf[ci] : 0.f;
-        const float ig = sigmoid_f(acc[rt][0] + g4.x), fg = sigmoid_f(acc[rt][1] + g4.y);
-        const float cg = tanhf(acc[rt][2] + g4.z), og = sigmoid_f(acc[rt][3] + g4.w);
+        const float ig = fast_sigmoid(acc[rt][0] + g4.x), fg = fast_sigmoid(acc[rt][1] + g4.y);
+        const float cg = fast_tanh(acc[rt][2] + g4.z), og = fast_sigmoid(acc[rt][3] + g4.w);
         const float cn = fg * cold + ig * cg;
-        const float hn = og * tanhf(cn);
+        const float hn = og * fast_tanh(cn);
         a.cbuf[ci] = cn;
         {
             __bf16 hb = (__bf16)hn, lb = (__bf16)(hn - (float)hb);
@@ -307,6 +311,7 @@ struct PersistArgs {
     SplitPtr out_split;
     const float *oscale, *oshift;
     int T, B, BG, BGr;               // BG: padded rows per group (multiple of 16), BGr: real rows per group
+    long long *dbg;                  // diagnostic builds only: per-workgroup cycle sums of the step phases (null in production)
 };
 
 typedef unsigned long long u64;
@@ -341,6 +346,7 @@ __global__ __launch_bounds__(H / 64 * 64, 1) void lstm_layer_persistent_kernel(P
             al[ks] = *reinterpret_cast<const bf16x8 *>(wl + ks * 32);
         }
     }
+    const float osc = a.oscale ? a.oscale[d * H + u] : 1.f, osh = a.oscale ? a.oshift[d * H + u] : 0.f;   // next layer's folded BatchNorm
     float cst[NBT];
 #pragma unroll
     for (int bt = 0; bt < NBT; bt++) cst[bt] = 0.f;
@@ -348,6 +354,8 @@ __global__ __launch_bounds__(H / 64 * 64, 1) void lstm_layer_persistent_kernel(P
     unsigned int *cnt = a.sync + team, *abortf = a.sync + 16;
     __syncthreads();
 
+    long long ph[6] = {0, 0, 0, 0, 0, 0}, tst = a.dbg ? (long long)__builtin_readcyclecounter() : 0;
+#define PSTAMP(i) do { if (a.dbg) { long long n_ = __builtin_readcyclecounter(); ph[i] += n_ - tst; tst = n_; } } while (0)
     for (int s = 0; s < T; s++) {
         const int t = d ? (T - 1 - s) : s;
         // gx of this step does not depend on h: issue it before the wait
@@ -379,17 +387,35 @@ __global__ __launch_bounds__(H / 64 * 64, 1) void lstm_layer_persistent_kernel(P
                 }
             }
             __syncthreads();
+            PSTAMP(0);
             if (s_fail) return;
-            // pull the team's panel (parity (s-1)&1) into LDS: 8-byte agent-scope loads, coalesced
-            const u64 *src = reinterpret_cast<const u64 *>(a.hx + ((size_t)(((s - 1) & 1) * 16 + team) * 2) * plane);
-            const int n8 = (int)(plane / 4);                        // 8-byte granules per plane
-            for (int q = tid; q < 2 * n8; q += NTH) {
-                const u64 v = ld_agent(src + q);
-                const int pl = q >= n8, qq = pl ? q - n8 : q;
-                const int row = qq / (H / 4), c8 = qq - row * (H / 4);
-                *reinterpret_cast<u64 *>((pl ? Pl : Ph) + row * ROWB + c8 * 8) = v;
+            // pull the team's panel (parity (s-1)&1) into LDS: 16-byte sc1 buffer loads (bypass this CU's L1, served by
+            // L2 / fabric), every load of the panel in flight before the first LDS write
+            {
+                const unsigned short *srcp = a.hx + ((size_t)(((s - 1) & 1) * 16 + team) * 2) * plane;
+                const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short *>(srcp), 0,
+                                                                                      (int)(2 * plane * sizeof(unsigned short)), 0x00020000);
+                constexpr int NLD = (2 * NBT * 16 * H / 8 + NTH - 1) / NTH;     // 16-byte chunks per thread
+                const int n16 = (int)(2 * plane / 8);
+                u32x4 pv[NLD];
+#pragma unroll
+                for (int i = 0; i < NLD; i++) {
+                    const int q = tid + NTH * i;
+                    pv[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (q < n16 ? q : n16 - 1) * 16, 0, 16 /* sc1 */);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < NLD; i++) {
+                    const int q = tid + NTH * i;
+                    if (q < n16) {
+                        const int pl = q >= n16 / 2, qq = pl ? q - n16 / 2 : q;
+                        const int row = qq / (H / 8), c16 = qq - row * (H / 8);
+                        *reinterpret_cast<u32x4 *>((pl ? Pl : Ph) + row * ROWB + c16 * 16) = pv[i];
+                    }
+                }
             }
             __syncthreads();
+            PSTAMP(1);
 #pragma unroll
             for (int ks = 0; ks < KS; ks++) {
 #pragma unroll
@@ -402,17 +428,20 @@ __global__ __launch_bounds__(H / 64 * 64, 1) void lstm_layer_persistent_kernel(P
                 }
             }
         }
+        PSTAMP(2);
         // cell update + publish h_s
         u64 *dst = reinterpret_cast<u64 *>(a.hx + ((size_t)((s & 1) * 16 + team) * 2) * plane);
+        float hcur[NBT];
 #pragma unroll
         for (int bt = 0; bt < NBT; bt++) {
             const int lb = bt * 16 + li, b = g * a.BGr + lb;
             const bool valid = lb < a.BGr && b < B;
-            const float ig = sigmoid_f(acc[bt][0] + g4[bt].x), fg = sigmoid_f(acc[bt][1] + g4[bt].y);
-            const float cg = tanhf(acc[bt][2] + g4[bt].z), og = sigmoid_f(acc[bt][3] + g4[bt].w);
+            const float ig = fast_sigmoid(acc[bt][0] + g4[bt].x), fg = fast_sigmoid(acc[bt][1] + g4[bt].y);
+            const float cg = fast_tanh(acc[bt][2] + g4[bt].z), og = fast_sigmoid(acc[bt][3] + g4[bt].w);
             const float cn = fg * cst[bt] + ig * cg;
-            const float hn = valid ? og * tanhf(cn) : 0.f;
+            const float hn = valid ? og * fast_tanh(cn) : 0.f;
             cst[bt] = cn;
+            hcur[bt] = hn;
             __bf16 hb = (__bf16)hn, lbf = (__bf16)(hn - (float)hb);
             const unsigned int hbits = *reinterpret_cast<unsigned short *>(&hb), lbits = *reinterpret_cast<unsigned short *>(&lbf);
             // gather the 4 units of this row tile (lanes li, li+16, li+32, li+48) into one 8-byte granule per plane
@@ -425,10 +454,22 @@ __global__ __launch_bounds__(H / 64 * 64, 1) void lstm_layer_persistent_kernel(P
                 st_agent(dst + e, hi4);
                 st_agent(dst + plane / 4 + e, lo4);
             }
-            if (valid) {
+        }
+        PSTAMP(3);
+        if (s + 1 < T) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every storing wave drains its write-through stores
+            __syncthreads();
+            if (tid == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        // layer outputs: plain stores, off the hand-off's critical path (they overlap the wait for the team)
+#pragma unroll
+        for (int bt = 0; bt < NBT; bt++) {
+            const int lb = bt * 16 + li, b = g * a.BGr + lb;
+            if (lb < a.BGr && b < B) {
+                const float hn = hcur[bt];
                 const size_t oi = ((size_t)t * B + b) * 2 * H + d * H + u;
                 if (a.out_raw) a.out_raw[oi] = hn;
-                const float ov = a.oscale ? hn * a.oscale[d * H + u] + a.oshift[d * H + u] : hn;
+                const float ov = a.oscale ? hn * osc + osh : hn;
                 if (a.out && a.out != a.out_raw) a.out[oi] = ov;
                 if (a.out_split.hi) {
                     __bf16 ob = (__bf16)ov, ol = (__bf16)(ov - (float)ob);
@@ -437,12 +478,9 @@ __global__ __launch_bounds__(H / 64 * 64, 1) void lstm_layer_persistent_kernel(P
                 }
             }
         }
-        if (s + 1 < T) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every storing wave drains its write-through stores
-            __syncthreads();
-            if (tid == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
+        PSTAMP(4);
     }
+    if (a.dbg && tid == 0) for (int i = 0; i < 6; i++) a.dbg[blockIdx.x * 6 + i] = ph[i];
 }
 
 template <int H, int NBT>
@@ -462,6 +500,7 @@ int launch_lstm_layer_persistent(const LstmStepArgs &s, unsigned short *hx, unsi
     a.gx = s.gx; a.whh = s.whh_split; a.hx = hx; a.sync = sync; a.err_flag = err_flag;
     a.out = s.out; a.out_raw = s.out_raw; a.out_split = s.out_split; a.oscale = s.oscale; a.oshift = s.oshift;
     a.T = s.T; a.B = s.B; a.BGr = (s.B + 7) / 8; a.BG = persistent_bg(s.B);
+    a.dbg = (getenv("MDD_LSTM_DBG") && s.T > 100) ? reinterpret_cast<long long *>(hx + (size_t)2 * 16 * 2 * a.BG * s.H) : nullptr;
     const int nbt = a.BG / 16;
     if (s.H == 384) {
         if (nbt == 1) return launch_persistent_t<384, 1>(a, st);
