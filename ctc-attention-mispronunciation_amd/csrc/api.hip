@@ -58,6 +58,7 @@ struct mdd_model {
     int W1() const { return (cfg.feat + 2 - 3) / 2 + 1; }
     int W2() const { return (W1() + 2 - 3) / 2 + 1; }
     int rnn_in() const { return cfg.channels * W2(); }
+    bool lstm_granule = true;   // persistent kernel with the data-tagged hand-off (MDD_LSTM=counter selects the counter form)
     bool lstm_persist = true;   // one persistent team-synchronised launch per BiLSTM layer (split-bf16 mode, >= 256 CUs, B <= 512)
     int n_cu = 0;
     unsigned int *sync_words = nullptr;
@@ -217,7 +218,7 @@ static int run_stage(mdd_model *m, int si, const float *x, int B, int T, const i
             a.out_split = x3 ? split_view(m->act_s[n & 1], rows * H2) : kNoSplit;
             a.oscale = m->bn_scale[n + 1]; a.oshift = m->bn_shift[n + 1];
         }
-        if (m->persist(B)) { info->launches = 1; return launch_lstm_layer_persistent(a, reinterpret_cast<unsigned short *>(m->hx.p), m->sync_words, m->err_flag, st); }
+        if (m->persist(B)) { info->launches = 1; return ((m->lstm_granule && B <= 256) ? launch_lstm_layer_granule : launch_lstm_layer_persistent)(a, reinterpret_cast<unsigned short *>(m->hx.p), m->sync_words, m->err_flag, st); }
         return launch_lstm_layer(a, st);
     }
     si -= 2 * nl;
@@ -239,7 +240,7 @@ static int run_stage(mdd_model *m, int si, const float *x, int B, int T, const i
         a.out_split = x3 ? split_view(m->text_s, trows * H2) : kNoSplit;
         a.T = L; a.B = B; a.H = H; a.packed = use_packed(m);
         a.whh_split = m->t_whh_s; a.hsplit = (x3 && m->lstm_x3) ? reinterpret_cast<unsigned short *>(m->hsplit.p) : nullptr;
-        if (m->persist(B)) { info->launches = 1; return launch_lstm_layer_persistent(a, reinterpret_cast<unsigned short *>(m->hx.p), m->sync_words, m->err_flag, st); }
+        if (m->persist(B)) { info->launches = 1; return ((m->lstm_granule && B <= 256) ? launch_lstm_layer_granule : launch_lstm_layer_persistent)(a, reinterpret_cast<unsigned short *>(m->hx.p), m->sync_words, m->err_flag, st); }
         return launch_lstm_layer(a, st);
     }
     case 3:
@@ -299,11 +300,13 @@ extern "C" int mdd_create(const mdd_config *cfg, int device, mdd_model **out) {
     const char *lx = getenv("MDD_LSTM");
     m->lstm_x3 = lx && !strcmp(lx, "x3");
     if (lx && !strcmp(lx, "step")) m->lstm_persist = false;
+    if (lx && !strcmp(lx, "counter")) m->lstm_granule = false;
     const char *g = getenv("MDD_GRAPH");
     m->use_graph = !(g && g[0] == '0');
     if (int rc = init_kernel_attributes()) { delete m; return rc; }
     if (int rc = init_lstm_attributes()) { delete m; return rc; }
     if (int rc = init_persistent_attributes()) { delete m; return rc; }
+    if (int rc = init_granule_attributes()) { delete m; return rc; }
     m->n_cu = prop.multiProcessorCount;
     hipError_t e = hipMalloc((void **)&m->err_flag, sizeof(int));
     if (e == hipSuccess) e = hipMemset(m->err_flag, 0, sizeof(int));
@@ -489,7 +492,7 @@ static int forward_prepare(mdd_model *m, const float *x_dev, int32_t B, int32_t 
                     (rc = ensure(m->act_s[1], rows * 2 * H)) || (rc = ensure(m->x_s, rows * 2 * H)) ||
                     (rc = ensure(m->embo_s, trows * c.emb_dim)) || (rc = ensure(m->text_s, trows * 2 * H)) ||
                     (rc = ensure(m->key_s, trows * 2 * H)) || (rc = ensure(m->hsplit, (size_t)4 * B * H)) ||
-                    (rc = ensure(m->hx, (size_t)2 * 16 * 2 * persistent_bg(B) * H / 2 + 64 + 256 * 6 * 2))))   // + diagnostic stamps
+                    (rc = ensure(m->hx, (size_t)2 * 32 * granule_bg(B) * H * 2 + 64 + 256 * 6 * 2))))   // u64 granules (covers the counter form too) + stamps
         return rc;
     if (m->taps) {
         m->tap_rnn.resize(c.layers);
@@ -590,7 +593,9 @@ extern "C" const float *mdd_tap(mdd_model *m, const char *name, int64_t *numel) 
         p = dst.p;
     }
     else if (n == "lstm_dbg" && m->hx.p) {   // diagnostic stamps of the last persistent layer launch (MDD_LSTM_DBG=1)
-        p = m->hx.p + (size_t)2 * 16 * 2 * persistent_bg(B) * m->cfg.hidden / 2; ne = 256 * 6 * 2;
+        p = (m->lstm_granule && B <= 256) ? m->hx.p + (size_t)2 * 32 * granule_bg(B) * m->cfg.hidden * 2
+                            : m->hx.p + (size_t)2 * 16 * 2 * persistent_bg(B) * m->cfg.hidden / 2;
+        ne = 256 * 6 * 2;
     }
     else if (n == "conv1") { p = m->seq0.p; ne = (int64_t)Tp * B * m->rnn_in(); }
     else if (n == "text") { p = m->text.p; ne = (int64_t)L * B * H2; }

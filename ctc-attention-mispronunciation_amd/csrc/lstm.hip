@@ -483,6 +483,205 @@ __global__ __launch_bounds__(H / 64 * 64, 1) void lstm_layer_persistent_kernel(P
     if (a.dbg && tid == 0) for (int i = 0; i < 6; i++) a.dbg[blockIdx.x * 6 + i] = ph[i];
 }
 
+// ---- persistent layer kernel, data-tagged hand-off ("the data IS the flag", Guideline 16 form R2).
+// Same team structure, but (1) a team is 8 workgroups (32 teams = 2 directions x 16 batch groups), each workgroup
+// owning 4H/8 gate rows: RTW row tiles per wave, fragments resident in registers; the panel a workgroup pulls per
+// step is half as tall; (2) h travels as 8-byte granules {tag = step+1, bf16 hi | bf16 lo}: the producer just
+// stores them write-through -- no drain, no barrier, no counter -- and the consumer re-reads its share of the panel
+// until every tag equals the epoch.  One L2 round trip replaces three (drain, counter add, poll).  The exchange
+// buffer is zeroed before every launch (tags are never 0), so replays cannot see a previous launch's tags.
+template <int H, int NBT, int RTW>
+__global__ __launch_bounds__(256, 1) void lstm_layer_granule_kernel(PersistArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int NTH = 256, KS = H / 32, ROWB = H * 2 + 16, RM = 4 * H / 8, BGC = NBT * 16;
+    static_assert(RM == 4 * RTW * 16, "4 waves x RTW row tiles must cover the workgroup's gate rows");
+    unsigned char *Ph = smem, *Pl = smem + (size_t)BGC * ROWB;
+    __shared__ int s_fail;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, kq = lane >> 4;
+    const int w = blockIdx.x, xl = w & 7, j = w >> 3;
+    const int team = xl * 4 + (j >> 3), member = j & 7;            // 8 members share blockIdx%8 (one XCD under round-robin)
+    const int d = team >> 4, g = team & 15;
+    const int B = a.B, T = a.T;
+    if (tid == 0) s_fail = 0;
+
+    bf16x8 ah[RTW][KS], al[RTW][KS];
+    int unit[RTW];
+    float osc[RTW], osh[RTW];
+#pragma unroll
+    for (int rt = 0; rt < RTW; rt++) {
+        const int r0 = member * RM + (wave * RTW + rt) * 16;
+        unit[rt] = (r0 >> 2) + kq;
+        osc[rt] = a.oscale ? a.oscale[d * H + unit[rt]] : 1.f;
+        osh[rt] = a.oscale ? a.oshift[d * H + unit[rt]] : 0.f;
+        const unsigned short *wh = a.whh.hi + ((size_t)d * 4 * H + r0 + li) * H + kq * 8;
+        const unsigned short *wl = a.whh.lo + ((size_t)d * 4 * H + r0 + li) * H + kq * 8;
+#pragma unroll
+        for (int ks = 0; ks < KS; ks++) {
+            ah[rt][ks] = *reinterpret_cast<const bf16x8 *>(wh + ks * 32);
+            al[rt][ks] = *reinterpret_cast<const bf16x8 *>(wl + ks * 32);
+        }
+    }
+    float cst[RTW][NBT];
+#pragma unroll
+    for (int rt = 0; rt < RTW; rt++)
+#pragma unroll
+        for (int bt = 0; bt < NBT; bt++) cst[rt][bt] = 0.f;
+    const size_t pgran = (size_t)BGC * H;                          // granules per (parity, team) panel
+    u64 *hxg = reinterpret_cast<u64 *>(a.hx);
+    unsigned int *abortf = a.sync + 16;
+    long long ph[6] = {0, 0, 0, 0, 0, 0}, tst = a.dbg ? (long long)__builtin_readcyclecounter() : 0;
+    __syncthreads();
+
+    for (int s = 0; s < T; s++) {
+        const int t = d ? (T - 1 - s) : s;
+        float4 g4[RTW][NBT];
+#pragma unroll
+        for (int rt = 0; rt < RTW; rt++)
+#pragma unroll
+            for (int bt = 0; bt < NBT; bt++) {
+                const int lb = bt * 16 + li, b = g * a.BGr + lb;
+                const bool valid = lb < a.BGr && b < B;
+                g4[rt][bt] = valid ? *reinterpret_cast<const float4 *>(a.gx + (((size_t)t * B + b) * 2 + d) * 4 * H + unit[rt] * 4)
+                                   : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        f32x4 acc[RTW][NBT];
+#pragma unroll
+        for (int rt = 0; rt < RTW; rt++)
+#pragma unroll
+            for (int bt = 0; bt < NBT; bt++) acc[rt][bt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (s > 0) {
+            // ---- sweep this thread's share of the team's panel (parity (s-1)&1) until every tag == s
+            const u64 *srcp = hxg + (size_t)(((s - 1) & 1) * 32 + team) * pgran;
+            const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<u64 *>(srcp), 0, (int)(pgran * 8), 0x00020000);
+            constexpr int NLD = BGC * H / 2 / NTH;                  // 16-byte chunks (2 granules) per thread
+            static_assert(BGC * H / 2 % NTH == 0, "panel must be whole passes of the workgroup");
+            unsigned need = (1u << NLD) - 1u;
+            const unsigned epoch = (unsigned)s;
+            int sweeps = 0;
+            const long long t0 = wall_clock64();
+            while (true) {
+                u32x4 pv[NLD];
+#pragma unroll
+                for (int i = 0; i < NLD; i++)
+                    if (need & (1u << i)) pv[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (tid + NTH * i) * 16, 0, 16 /* sc1 */);
+#pragma unroll
+                for (int i = 0; i < NLD; i++)
+                    if ((need & (1u << i)) && pv[i][0] == epoch && pv[i][2] == epoch) {
+                        need &= ~(1u << i);
+                        const int q = tid + NTH * i, row = (2 * q) / H, k = 2 * q - row * H;
+                        *reinterpret_cast<unsigned int *>(Ph + row * ROWB + k * 2) = (pv[i][1] & 0xffffu) | (pv[i][3] << 16);
+                        *reinterpret_cast<unsigned int *>(Pl + row * ROWB + k * 2) = (pv[i][1] >> 16) | (pv[i][3] & 0xffff0000u);
+                    }
+                if (__all(need == 0)) break;
+                if ((++sweeps & 63) == 0) {
+                    int bad = 0;
+                    if (lane == 0) bad = (__hip_atomic_load(abortf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) || (wall_clock64() - t0 > 200000000ll);
+                    if (__any(bad)) {
+                        if (lane == 0) { __hip_atomic_store(abortf, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); atomicExch(a.err_flag, 2); s_fail = 1; }
+                        break;
+                    }
+                }
+            }
+            __syncthreads();
+            PSTAMP(0);
+            if (s_fail) return;
+#pragma unroll
+            for (int ks = 0; ks < KS; ks++) {
+#pragma unroll
+                for (int bt = 0; bt < NBT; bt++) {
+                    const bf16x8 bh = *reinterpret_cast<const bf16x8 *>(Ph + (bt * 16 + li) * ROWB + ks * 64 + kq * 16);
+                    const bf16x8 bl = *reinterpret_cast<const bf16x8 *>(Pl + (bt * 16 + li) * ROWB + ks * 64 + kq * 16);
+                    // product-major order: consecutive MFMAs hit different accumulators (no dependent-issue stall);
+                    // each accumulator still sees ah.bl, al.bh, ah.bh in that order (bit-identical to the step kernel)
+#pragma unroll
+                    for (int rt = 0; rt < RTW; rt++) acc[rt][bt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[rt][ks], bl, acc[rt][bt], 0, 0, 0);
+#pragma unroll
+                    for (int rt = 0; rt < RTW; rt++) acc[rt][bt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[rt][ks], bh, acc[rt][bt], 0, 0, 0);
+#pragma unroll
+                    for (int rt = 0; rt < RTW; rt++) acc[rt][bt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[rt][ks], bh, acc[rt][bt], 0, 0, 0);
+                }
+            }
+            __syncthreads();   // every wave is done with the LDS panel before the next step's sweep overwrites it
+        }
+        PSTAMP(2);
+        // ---- cell update; publish h_s as tagged granules (no drain, no signal)
+        u64 *dst = hxg + (size_t)((s & 1) * 32 + team) * pgran;
+        float hcur[RTW][NBT];
+#pragma unroll
+        for (int rt = 0; rt < RTW; rt++)
+#pragma unroll
+            for (int bt = 0; bt < NBT; bt++) {
+                const int lb = bt * 16 + li, b = g * a.BGr + lb;
+                const bool valid = lb < a.BGr && b < B;
+                const float ig = fast_sigmoid(acc[rt][bt][0] + g4[rt][bt].x), fg = fast_sigmoid(acc[rt][bt][1] + g4[rt][bt].y);
+                const float cg = fast_tanh(acc[rt][bt][2] + g4[rt][bt].z), og = fast_sigmoid(acc[rt][bt][3] + g4[rt][bt].w);
+                const float cn = fg * cst[rt][bt] + ig * cg;
+                const float hn = valid ? og * fast_tanh(cn) : 0.f;
+                cst[rt][bt] = cn;
+                hcur[rt][bt] = hn;
+                __bf16 hb = (__bf16)hn, lbf = (__bf16)(hn - (float)hb);
+                const unsigned int data = (unsigned int)*reinterpret_cast<unsigned short *>(&hb) | ((unsigned int)*reinterpret_cast<unsigned short *>(&lbf) << 16);
+                if (s + 1 < T) st_agent(dst + (size_t)lb * H + unit[rt], (u64)(unsigned)(s + 1) | ((u64)data << 32));
+            }
+        PSTAMP(3);
+#pragma unroll
+        for (int rt = 0; rt < RTW; rt++)
+#pragma unroll
+            for (int bt = 0; bt < NBT; bt++) {
+                const int lb = bt * 16 + li, b = g * a.BGr + lb;
+                if (lb < a.BGr && b < B) {
+                    const float hn = hcur[rt][bt];
+                    const size_t oi = ((size_t)t * B + b) * 2 * H + d * H + unit[rt];
+                    if (a.out_raw) a.out_raw[oi] = hn;
+                    const float ov = hn * osc[rt] + osh[rt];
+                    if (a.out && a.out != a.out_raw) a.out[oi] = ov;
+                    if (a.out_split.hi) {
+                        __bf16 ob = (__bf16)ov, ol = (__bf16)(ov - (float)ob);
+                        a.out_split.hi[oi] = *reinterpret_cast<unsigned short *>(&ob);
+                        a.out_split.lo[oi] = *reinterpret_cast<unsigned short *>(&ol);
+                    }
+                }
+            }
+        PSTAMP(4);
+    }
+    if (a.dbg && tid == 0) for (int i = 0; i < 6; i++) a.dbg[blockIdx.x * 6 + i] = ph[i];
+}
+
+int granule_bg(int B) { const int r = (B + 15) / 16; return r <= 16 ? 16 : 32; }   // rows per batch group (16 groups), padded
+
+template <int H, int NBT, int RTW>
+static int launch_granule_t(PersistArgs a, hipStream_t st) {
+    constexpr int ROWB = H * 2 + 16;
+    const size_t smem = (size_t)2 * NBT * 16 * ROWB;
+    MDD_HIP_CHECK(hipMemsetAsync(a.sync, 0, 32 * sizeof(unsigned int), st));
+    MDD_HIP_CHECK(hipMemsetAsync(a.hx, 0, (size_t)2 * 32 * NBT * 16 * H * 8, st));   // tags must start at 0 on every launch
+    hipLaunchKernelGGL((lstm_layer_granule_kernel<H, NBT, RTW>), dim3(256), dim3(256), smem, st, a);
+    MDD_LAUNCH_CHECK();
+    return MDD_OK;
+}
+
+int launch_lstm_layer_granule(const LstmStepArgs &s, unsigned short *hx, unsigned int *sync, int *err_flag, hipStream_t st) {
+    PersistArgs a;
+    a.gx = s.gx; a.whh = s.whh_split; a.hx = hx; a.sync = sync; a.err_flag = err_flag;
+    a.out = s.out; a.out_raw = s.out_raw; a.out_split = s.out_split; a.oscale = s.oscale; a.oshift = s.oshift;
+    a.T = s.T; a.B = s.B; a.BGr = (s.B + 15) / 16; a.BG = granule_bg(s.B);
+    a.dbg = (getenv("MDD_LSTM_DBG") && s.T > 100) ? reinterpret_cast<long long *>(reinterpret_cast<u64 *>(hx) + (size_t)2 * 32 * a.BG * s.H) : nullptr;
+    if (a.oscale == nullptr) a.oshift = nullptr;
+    const int nbt = a.BG / 16;
+    if (s.H == 384) return nbt == 1 ? launch_granule_t<384, 1, 3>(a, st) : launch_granule_t<384, 2, 3>(a, st);
+    if (s.H == 256) return nbt == 1 ? launch_granule_t<256, 1, 2>(a, st) : launch_granule_t<256, 2, 2>(a, st);
+    set_error("granule lstm: unsupported H=%d", s.H);
+    return MDD_ERR_ARG;
+}
+
+int init_granule_attributes() {
+#define GATTR(H, N, R) MDD_HIP_CHECK(hipFuncSetAttribute((const void *)lstm_layer_granule_kernel<H, N, R>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024))
+    GATTR(384, 1, 3); GATTR(384, 2, 3); GATTR(256, 1, 2); GATTR(256, 2, 2);
+#undef GATTR
+    return MDD_OK;
+}
+
 template <int H, int NBT>
 static int launch_persistent_t(const PersistArgs &a, hipStream_t st) {
     constexpr int ROWB = H * 2 + 16;

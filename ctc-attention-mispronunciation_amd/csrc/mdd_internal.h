@@ -78,6 +78,10 @@ int init_persistent_attributes();
 // One launch for the whole layer (256 co-resident workgroups, team-synchronised; see lstm.hip).  hx: exchange buffer
 // of 2*16*2*persistent_bg(B)*H ushorts, sync: 32 uints.  Requires B <= 512, H in {256, 384}, >= 256 CUs.
 int persistent_bg(int B);
+int granule_bg(int B);
+int init_granule_attributes();
+// data-tagged variant (8-workgroup teams, no counter): hx = 2*32*granule_bg(B)*H u64 granules (+ stamps), sync: 32 uints
+int launch_lstm_layer_granule(const LstmStepArgs &s, unsigned short *hx, unsigned int *sync, int *err_flag, hipStream_t st);
 int launch_lstm_layer_persistent(const LstmStepArgs &s, unsigned short *hx, unsigned int *sync, int *err_flag, hipStream_t st);
 
 }  // namespace mdd
