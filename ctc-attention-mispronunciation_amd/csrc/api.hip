@@ -45,7 +45,7 @@ struct mdd_model {
     float *w_score = nullptr, *fscale = nullptr, *fshift = nullptr, *w_fc = nullptr, *w_fcp = nullptr;
     std::vector<mdd::SplitPtr> wih_s, whh_s;                // split-bf16 copies of the GEMM / recurrent weights
     mdd::SplitPtr t_whh_s{nullptr, nullptr};
-    mdd::SplitPtr t_wih_s{nullptr, nullptr}, w_score_s{nullptr, nullptr};
+    mdd::SplitPtr t_wih_s{nullptr, nullptr}, w_score_s{nullptr, nullptr}, w_conv1_s{nullptr, nullptr};
     std::vector<void *> owned;  // every hipMalloc'd weight pointer
     // workspace
     mdd::DevBuf y0, seq0, gx, act[2], xraw, hbuf, cbuf, embo, text, key, S;
@@ -63,6 +63,7 @@ struct mdd_model {
     int n_cu = 0;
     unsigned int *sync_words = nullptr;
     bool lstm_x3 = false;   // MDD_LSTM=x3: LDS-tiled split-bf16 step kernel (measured slower than the packed fp32 step; kept for study)
+    bool conv_fused() const { return x3() && cfg.feat == 243 && cfg.channels == 32; }
     bool persist(int B) const { return x3() && lstm_persist && !lstm_x3 && n_cu >= 256 && B <= 512; }
     bool x3() const {   // the bf16x3 GEMM needs K % 32 == 0 for every contraction and the packed LSTM layouts
         return precision == 1 && (cfg.hidden == 384 || cfg.hidden == 256) && rnn_in() % 32 == 0 && cfg.emb_dim % 32 == 0;
@@ -185,6 +186,13 @@ static int run_stage(mdd_model *m, int si, const float *x, int B, int T, const i
     static thread_local char namebuf[32];
     Stage dummy; if (!info) info = &dummy;
     info->launches = 1; info->flops = 0.0;
+    if (si == 0 && m->conv_fused()) {   // conv0 recomputed per output row (x1.5) + conv1 as implicit GEMM, one kernel
+        info->name = "conv_fused";
+        info->flops = 2.0 * 9 * c.channels * (double)B * Tp * m->W2() * (c.channels + 6.0);
+        return launch_conv_fused(x, m->w_conv0, m->sc0, m->sh0, m->w_conv1_s, m->sc1, m->sh1, split_view(m->seq0_s, rows * m->rnn_in()),
+                                 nullptr, B, T, st);
+    }
+    if (si == 1 && m->conv_fused()) { info->name = "conv1_in_fused"; info->launches = 0; return MDD_OK; }
     if (si == 0) { info->name = "conv0"; info->flops = 2.0 * 9 * c.channels * (double)B * T * m->W1();
         return launch_conv0(x, m->w_conv0, m->sc0, m->sh0, m->y0.p, B, T, c.feat, c.channels, st); }
     if (si == 1) { info->name = "conv1"; info->flops = 2.0 * 9 * c.channels * c.channels * (double)B * Tp * m->W2();
@@ -307,6 +315,7 @@ extern "C" int mdd_create(const mdd_config *cfg, int device, mdd_model **out) {
     if (int rc = init_lstm_attributes()) { delete m; return rc; }
     if (int rc = init_persistent_attributes()) { delete m; return rc; }
     if (int rc = init_granule_attributes()) { delete m; return rc; }
+    if (int rc = init_conv_attributes()) { delete m; return rc; }
     m->n_cu = prop.multiProcessorCount;
     hipError_t e = hipMalloc((void **)&m->err_flag, sizeof(int));
     if (e == hipSuccess) e = hipMemset(m->err_flag, 0, sizeof(int));
@@ -370,6 +379,12 @@ extern "C" int mdd_finalize_weights(mdd_model *m) {
             for (int ci = 0; ci < ch; ci++)
                 for (int k = 0; k < 9; k++) tmp[((size_t)ci * 9 + k) * ch + co] = (*w1)[((size_t)co * ch + ci) * 9 + k];
         if ((rc = upload(m, tmp, &m->w_conv1t)) || (rc = upload(m, sc, &m->sc1)) || (rc = upload(m, sh, &m->sh1))) return rc;
+        // conv1 weights for the fused MFMA front-end: [co][kh][kw][ci] (k = (kh*3+kw)*ch + ci), split-bf16
+        tmp.assign((size_t)ch * 9 * ch, 0.f);
+        for (int co = 0; co < ch; co++)
+            for (int ci = 0; ci < ch; ci++)
+                for (int k = 0; k < 9; k++) tmp[((size_t)co * 9 + k) * ch + ci] = (*w1)[((size_t)co * ch + ci) * 9 + k];
+        if ((rc = upload_split(m, tmp, &m->w_conv1_s))) return rc;
     }
     for (int n = 0; n < c.layers; n++) {
         char base[64];
@@ -482,7 +497,7 @@ static int forward_prepare(mdd_model *m, const float *x_dev, int32_t B, int32_t 
     const int H = c.hidden, Tp = T / 2;
     int rc;
     const size_t rows = (size_t)Tp * B, trows = (size_t)L * B, mrows = rows > trows ? rows : trows;
-    if ((rc = ensure(m->y0, (size_t)B * c.channels * T * m->W1())) || (rc = ensure(m->seq0, rows * m->rnn_in())) ||
+    if ((!m->conv_fused() && (rc = ensure(m->y0, (size_t)B * c.channels * T * m->W1()))) || (rc = ensure(m->seq0, rows * m->rnn_in())) ||
         (rc = ensure(m->gx, mrows * 8 * H)) || (rc = ensure(m->act[0], rows * 2 * H)) || (rc = ensure(m->act[1], rows * 2 * H)) ||
         (rc = ensure(m->xraw, rows * 2 * H)) || (rc = ensure(m->hbuf, (size_t)4 * ((B + 15) / 16 * 16) * H)) || (rc = ensure(m->cbuf, (size_t)2 * ((B + 15) / 16 * 16) * H)) ||
         (rc = ensure(m->embo, trows * c.emb_dim)) || (rc = ensure(m->text, trows * 2 * H)) || (rc = ensure(m->key, trows * 2 * H)) ||
@@ -556,6 +571,13 @@ extern "C" int mdd_forward_profile(mdd_model *m, const float *x_dev, int32_t B, 
         rc = run_stage(m, si, x_dev, B, T, x1_dev, L, logp_dev, m->cap_stream, &info);
         hipError_t e = hipStreamEndCapture(m->cap_stream, &graph);
         if (rc || e != hipSuccess) { if (graph) (void)hipGraphDestroy(graph); if (!rc) set_error("stage capture failed"); return rc ? rc : MDD_ERR_HIP; }
+        if (info.launches == 0) {   // stage folded into a neighbour in this configuration
+            (void)hipGraphDestroy(graph);
+            ms[si] = 0.f; launches[si] = 0; flops[si] = 0.0;
+            if (si) all += ",";
+            all += info.name;
+            continue;
+        }
         hipGraphExec_t exec = nullptr;
         e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
         (void)hipGraphDestroy(graph);

@@ -157,4 +157,166 @@ int launch_conv1(const float *y0, const float *w_t, const float *scale, const fl
     return MDD_OK;
 }
 
+// ---------------------------------------------------------------- fused conv0 -> conv1 (split-bf16 MFMA)
+// One pass over x produces the BiLSTM input rows directly: conv0 (+BN+ReLU) is recomputed per output row into LDS
+// (3 conv0 rows x 122 columns x 32 channels, bf16 hi/lo) and conv1 runs as an implicit GEMM on the bf16 matrix cores
+//   out[w', co] = sum_k A[w', k] . W1[co, k],   k = (kh, kw, ci), K = 288,  M = 61 (two 32-row tiles),  N = 32
+// with the bf16x3 product form.  The 500 MB-per-batch conv0 activation (y0) never exists in HBM: the kernel reads
+// x once (5 rows per output row) and writes the [T'*B, 1952] split-bf16 rows the input projection consumes.
+// A workgroup is persistent over output rows (grid-stride), so its W1 fragments stay in registers.
+// LDS: x tile [5][248] f32 | y0 hi/lo [3][124 cols][80 B] (32 ch x bf16 + 16 B pad: 2-way-conflict fragment reads)
+//      | K-half reduction [2][32x32] f32 | output row [1952] hi, lo.
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int CF_XLD = 248, CF_COLB = 80, CF_NCOL = 124, CF_YPLANE = 3 * CF_NCOL * CF_COLB;   // 29760 B
+
+__global__ __launch_bounds__(256, 2) void conv_fused_kernel(const float *__restrict__ x, const float *__restrict__ w0,
+                                                            const float *__restrict__ sc0, const float *__restrict__ sh0,
+                                                            const unsigned short *__restrict__ w1h, const unsigned short *__restrict__ w1l,
+                                                            const float *__restrict__ sc1, const float *__restrict__ sh1,
+                                                            unsigned short *__restrict__ out_hi, unsigned short *__restrict__ out_lo,
+                                                            float *__restrict__ out_f32, int B, int T) {
+    constexpr int F = 243, W1 = 122, W2 = 61, CH = 32, ROW = CH * W2;   // 1952
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float *xs = reinterpret_cast<float *>(smem);                                   // [5][CF_XLD]
+    unsigned char *yh = smem + 5 * CF_XLD * 4, *yl = yh + CF_YPLANE;               // conv0 tile, hi / lo
+    float *red = reinterpret_cast<float *>(yl + CF_YPLANE);                        // [2][1024]
+    unsigned short *oh = reinterpret_cast<unsigned short *>(red + 2048), *ol = oh + ROW;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int mt = wave & 1, kh2 = wave >> 1;                                      // M tile, K half of this wave
+    const int li = lane & 31, half = lane >> 5;
+    const int Tp = T / 2;
+
+    // resident B fragments: W1[co = li][k], this wave's 9 k-steps of 16
+    bf16x8 bwh[9], bwl[9];
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        const int kb = kh2 * 9 + i;
+        bwh[i] = *reinterpret_cast<const bf16x8 *>(w1h + (size_t)li * 288 + kb * 16 + half * 8);
+        bwl[i] = *reinterpret_cast<const bf16x8 *>(w1l + (size_t)li * 288 + kb * 16 + half * 8);
+    }
+    // zero the left pad column of the conv0 tile once (wcol = -1)
+    for (int i = tid; i < 3 * 2 * CF_COLB / 4; i += 256) {
+        const int r = i / (2 * CF_COLB / 4), rem = i - r * (2 * CF_COLB / 4);
+        reinterpret_cast<unsigned int *>((rem < CF_COLB / 4 ? yh : yl) + r * CF_NCOL * CF_COLB)[rem % (CF_COLB / 4)] = 0u;
+    }
+
+    for (int rowid = blockIdx.x; rowid < Tp * B; rowid += gridDim.x) {
+        const int tp = rowid / B, b = rowid - tp * B;
+        __syncthreads();                                                           // previous row's LDS fully consumed
+        // ---- x rows 2tp-2 .. 2tp+2, columns -1 .. 243 (zero outside)
+        for (int i = tid; i < 5 * CF_XLD; i += 256) {
+            const int r = i / CF_XLD, c = i - r * CF_XLD - 1, ti = 2 * tp - 2 + r;
+            xs[i] = (ti >= 0 && ti < T && c >= 0 && c < F) ? x[((size_t)b * T + ti) * F + c] : 0.f;
+        }
+        __syncthreads();
+        // ---- conv0 + BN + ReLU -> bf16 hi/lo, layout [r][wcol+1][ci]
+        for (int p = tid; p < 3 * W1; p += 256) {
+            const int r = p / W1, wc = p - r * W1, ti = 2 * tp - 1 + r;
+            const bool rowok = ti >= 0 && ti < T;
+            float in[9];
+#pragma unroll
+            for (int kh = 0; kh < 3; kh++)
+#pragma unroll
+                for (int kw = 0; kw < 3; kw++) in[kh * 3 + kw] = xs[(r + kh) * CF_XLD + 2 * wc + kw];   // x col 2wc+kw-1, +1 pad
+            unsigned char *dh = yh + (r * CF_NCOL + wc + 1) * CF_COLB, *dl = yl + (r * CF_NCOL + wc + 1) * CF_COLB;
+#pragma unroll
+            for (int cg = 0; cg < 4; cg++) {
+                unsigned int hw[4], lw[4];
+#pragma unroll
+                for (int cp = 0; cp < 4; cp++) {
+                    float v[2];
+#pragma unroll
+                    for (int e = 0; e < 2; e++) {
+                        const int c = cg * 8 + cp * 2 + e;
+                        float acc = 0.f;
+#pragma unroll
+                        for (int j = 0; j < 9; j++) acc = fmaf(in[j], w0[c * 9 + j], acc);
+                        acc = acc * sc0[c] + sh0[c];
+                        v[e] = (rowok && acc > 0.f) ? acc : 0.f;
+                    }
+                    __bf16 h0 = (__bf16)v[0], h1 = (__bf16)v[1];
+                    __bf16 l0 = (__bf16)(v[0] - (float)h0), l1 = (__bf16)(v[1] - (float)h1);
+                    hw[cp] = (unsigned int)*reinterpret_cast<unsigned short *>(&h0) | ((unsigned int)*reinterpret_cast<unsigned short *>(&h1) << 16);
+                    lw[cp] = (unsigned int)*reinterpret_cast<unsigned short *>(&l0) | ((unsigned int)*reinterpret_cast<unsigned short *>(&l1) << 16);
+                }
+                *reinterpret_cast<u32x4 *>(dh + cg * 16) = (u32x4){hw[0], hw[1], hw[2], hw[3]};
+                *reinterpret_cast<u32x4 *>(dl + cg * 16) = (u32x4){lw[0], lw[1], lw[2], lw[3]};
+            }
+        }
+        __syncthreads();
+        // ---- conv1: this wave = M tile mt (w' = mt*32 + li), K half kh2
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[r] = 0.f;
+        const int m = min(mt * 32 + li, W2 - 1);                                   // rows >= 61 recompute row 60, never stored
+#pragma unroll
+        for (int i = 0; i < 9; i++) {
+            const int kb = kh2 * 9 + i, kk = kb >> 1, kh = kk / 3, kw = kk - kh * 3;
+            const int off = (kh * CF_NCOL + 2 * m + kw) * CF_COLB + ((kb & 1) * 16 + half * 8) * 2;   // col index = (2m+kw-1)+1
+            const bf16x8 ah = *reinterpret_cast<const bf16x8 *>(yh + off);
+            const bf16x8 al = *reinterpret_cast<const bf16x8 *>(yl + off);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bwl[i], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bwh[i], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bwh[i], acc, 0, 0, 0);
+        }
+        // ---- reduce the two K halves, BN + ReLU, transpose to the output row through LDS
+        if (kh2 == 1) {
+#pragma unroll
+            for (int r = 0; r < 16; r++) red[mt * 1024 + r * 64 + lane] = acc[r];
+        }
+        __syncthreads();
+        if (kh2 == 0) {
+            const float s1 = sc1[li], h1 = sh1[li];                                 // C/D: col = lane&31 = co
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int wo = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;         // row = w'
+                if (wo < W2) {
+                    float v = (acc[r] + red[mt * 1024 + r * 64 + lane]) * s1 + h1;
+                    v = v > 0.f ? v : 0.f;
+                    __bf16 hb = (__bf16)v, lb = (__bf16)(v - (float)hb);
+                    oh[li * W2 + wo] = *reinterpret_cast<unsigned short *>(&hb);
+                    ol[li * W2 + wo] = *reinterpret_cast<unsigned short *>(&lb);
+                }
+            }
+        }
+        __syncthreads();
+        // ---- coalesced row store: 1952 bf16 = 244 x 16 B per plane
+        {
+            const size_t base = (size_t)rowid * ROW;
+            if (tid < 244) *reinterpret_cast<u32x4 *>(out_hi + base + tid * 8) = *reinterpret_cast<const u32x4 *>(oh + tid * 8);
+            else if (tid - 244 < 12) {   // 12 threads left in this pass: start the lo plane
+                const int q = tid - 244;
+                *reinterpret_cast<u32x4 *>(out_lo + base + q * 8) = *reinterpret_cast<const u32x4 *>(ol + q * 8);
+            }
+            if (tid < 232) {
+                const int q = tid + 12;
+                *reinterpret_cast<u32x4 *>(out_lo + base + q * 8) = *reinterpret_cast<const u32x4 *>(ol + q * 8);
+            }
+            if (out_f32)
+                for (int i = tid; i < ROW; i += 256)
+                    out_f32[base + i] = __uint_as_float((unsigned)oh[i] << 16) + __uint_as_float((unsigned)ol[i] << 16);
+        }
+    }
+}
+
+size_t conv_fused_smem() { return 5 * CF_XLD * 4 + 2 * (size_t)CF_YPLANE + 2048 * 4 + 2 * 1952 * 2; }
+
+int launch_conv_fused(const float *x, const float *w0, const float *sc0, const float *sh0, SplitPtr w1, const float *sc1,
+                      const float *sh1, SplitPtr out, float *out_f32, int B, int T, hipStream_t st) {
+    const int rows = (T / 2) * B;
+    int grid = rows < 2048 ? rows : 2048;
+    hipLaunchKernelGGL(conv_fused_kernel, dim3(grid), dim3(256), conv_fused_smem(), st, x, w0, sc0, sh0, w1.hi, w1.lo, sc1, sh1,
+                       out.hi, out.lo, out_f32, B, T);
+    MDD_LAUNCH_CHECK();
+    return MDD_OK;
+}
+
+int init_conv_attributes() {
+    MDD_HIP_CHECK(hipFuncSetAttribute((const void *)conv_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+    return MDD_OK;
+}
+
 }  // namespace mdd
