@@ -316,6 +316,7 @@ extern "C" int mdd_create(const mdd_config *cfg, int device, mdd_model **out) {
     if (int rc = init_persistent_attributes()) { delete m; return rc; }
     if (int rc = init_granule_attributes()) { delete m; return rc; }
     if (int rc = init_conv_attributes()) { delete m; return rc; }
+    if (int rc = init_gemm_attributes()) { delete m; return rc; }
     m->n_cu = prop.multiProcessorCount;
     hipError_t e = hipMalloc((void **)&m->err_flag, sizeof(int));
     if (e == hipSuccess) e = hipMemset(m->err_flag, 0, sizeof(int));

@@ -14,46 +14,61 @@
 // would and spends no VALU on conversion.
 //
 // Tiling: 128x128 block tile, BK = 32, 256 threads = 4 waves (2x2), each wave 64x64 = 2x2 MFMA tiles of
-// 32x32 (64 accumulator VGPRs), 24 MFMAs per wave per K-tile.  Four bf16 planes (A hi/lo, W hi/lo) are
-// staged global -> registers -> LDS with the next K-tile's loads in flight during the MFMAs (two LDS
-// stages, one barrier per K-tile).  LDS rows are padded from 64 to 80 bytes: the ds_read_b128 fragment
-// reads (lane = row, half-wave = 16-byte k-slice) and the ds_write_b128 staging writes are conflict-free.
+// 32x32 (64 accumulator VGPRs), 24 MFMAs per wave per K-tile, 2 workgroups per CU.  Four bf16 planes (A hi/lo,
+// W hi/lo) are staged global -> registers -> LDS; loads are issued per PAIR of K-tiles (whole 128-byte lines)
+// one pair ahead of the MFMAs (two LDS stages, one barrier per K-tile).
 #include "mdd_internal.h"
 
 namespace mdd {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int XBM = 128, XBN = 128, XBK = 32, XROW = 80;   // XROW: bytes per LDS row (64 data + 16 pad)
-constexpr int XPLANE = XBM * XROW;                          // 10240 B
+constexpr int XBM = 128, XBN = 128, XBK = 32, XROW = 64;   // XROW: bytes per LDS row (32 bf16, unpadded, XOR-swizzled)
+constexpr int XPLANE = XBM * XROW;                          // 8192 B
+// LDS layout: 16-byte chunk c of row r lives at chunk position c ^ ((r >> 2) & 3): the ds_read_b128 fragment reads
+// (16-lane groups {0-3,12-15,20-27}, ..: rows sharing r&3 differ in (r>>2)&3) and the ds_write_b128 staging writes are
+// bank-conflict-free.
+//
+// Global loads fetch PAIRS of K-tiles: a thread's 16-byte chunk q covers (row q/8, chunk q%8) of a 128-byte line, so 8
+// consecutive lanes read one whole line.  (Fetching one 32-wide K-tile at a time touches half lines whose other half
+// is evicted from the 32 KB L1 before the next K-tile wants it: the kernel is bound by the L2->L1->LDS fill path, not
+// by the matrix cores -- tools/gemm_ablation.py: matrix cores + LDS reads alone 1.15 ms, data movement alone 2.18 ms
+// at M=64000, N=3072, K=1952.)  Chunks 0-3 of a line belong to the even K-tile of the pair, 4-7 to the odd one.
+constexpr int XPL = XBM * 8 / 256;                          // pair-chunks per thread per plane (4)
 
-__device__ __forceinline__ void x3_load_stage(const unsigned short *__restrict__ Ph, const unsigned short *__restrict__ Pl,
-                                              int ld, int rows_total, int row0, int k0, int tid, uint4 (&rh)[2], uint4 (&rl)[2]) {
+__device__ __forceinline__ void x3_load_pair(const unsigned short *__restrict__ Ph, const unsigned short *__restrict__ Pl, int ld,
+                                             int rows_total, int K, int row0, int k0, int tid, u32x4 (&rh)[XPL], u32x4 (&rl)[XPL]) {
+    // branch-free: rows past the edge are clamped (their products land in C rows/cols that are never stored); chunks past
+    // K (K % 64 == 32 tails) read a valid address and are zeroed
 #pragma unroll
-    for (int i = 0; i < 2; i++) {
-        const int q = tid + 256 * i, row = row0 + (q >> 2), c = q & 3;
-        uint4 vh = make_uint4(0, 0, 0, 0), vl = vh;
-        if (row < rows_total) {
-            const size_t off = (size_t)row * ld + k0 + c * 8;
-            vh = *reinterpret_cast<const uint4 *>(Ph + off);
-            vl = *reinterpret_cast<const uint4 *>(Pl + off);
-        }
-        rh[i] = vh; rl[i] = vl;
+    for (int i = 0; i < XPL; i++) {
+        const int q = tid + 256 * i, row = min(row0 + (q >> 3), rows_total - 1), k = k0 + (q & 7) * 8;
+        const size_t off = (size_t)row * ld + min(k, K - 8);
+        const u32x4 vh = *reinterpret_cast<const u32x4 *>(Ph + off), vl = *reinterpret_cast<const u32x4 *>(Pl + off);
+        const u32x4 z = {0u, 0u, 0u, 0u};
+        rh[i] = k < K ? vh : z;
+        rl[i] = k < K ? vl : z;
     }
 }
 
-__device__ __forceinline__ void x3_store_stage(unsigned char *ph, unsigned char *pl, int tid, const uint4 (&rh)[2], const uint4 (&rl)[2]) {
+// store the even (odd = 0) or odd (odd = 1) K-tile of a loaded pair into one LDS stage: lanes whose chunk belongs to the
+// other half skip the write (q & 4 selects the half; 4 consecutive lanes = 64 contiguous bytes of a row)
+__device__ __forceinline__ void x3_store_half(unsigned char *ph, unsigned char *pl, int tid, int odd, const u32x4 (&rh)[XPL], const u32x4 (&rl)[XPL]) {
 #pragma unroll
-    for (int i = 0; i < 2; i++) {
-        const int q = tid + 256 * i, off = (q >> 2) * XROW + (q & 3) * 16;
-        *reinterpret_cast<uint4 *>(ph + off) = rh[i];
-        *reinterpret_cast<uint4 *>(pl + off) = rl[i];
+    for (int i = 0; i < XPL; i++) {
+        const int q = tid + 256 * i, row = q >> 3, c8 = q & 7;
+        if ((c8 >> 2) == odd) {
+            const int off = row * XROW + (((c8 & 3) ^ ((row >> 2) & 3)) << 4);
+            *reinterpret_cast<u32x4 *>(ph + off) = rh[i];
+            *reinterpret_cast<u32x4 *>(pl + off) = rl[i];
+        }
     }
 }
 
 __device__ __forceinline__ bf16x8 x3_frag(const unsigned char *plane, int row, int kbyte) {
-    return *reinterpret_cast<const bf16x8 *>(plane + row * XROW + kbyte);
+    return *reinterpret_cast<const bf16x8 *>(plane + row * XROW + ((((kbyte >> 4) ^ ((row >> 2) & 3))) << 4));
 }
 
 __device__ __forceinline__ unsigned short bf16_bits(float x) {   // round-to-nearest-even, NaN-preserving cast
@@ -62,8 +77,9 @@ __device__ __forceinline__ unsigned short bf16_bits(float x) {   // round-to-nea
 }
 __device__ __forceinline__ float bf16_to_f32(unsigned short b) { return __uint_as_float((unsigned)b << 16); }
 
-// EPI 0: fp32 C (+bias).  EPI 1: split-bf16 C (hi/lo planes, same ldc).
-template <int EPI>
+// EPI 0: fp32 C (+bias).  EPI 1: split-bf16 C (hi/lo planes, same ldc).  ABL: ablation bits for tools/gemm_ablation.py
+// (1: no MFMA, 2: no global loads in the loop, 4: no LDS stores in the loop); 0 in the product.
+template <int EPI, int ABL = 0>
 __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(const unsigned short *__restrict__ Ah, const unsigned short *__restrict__ Al,
                                                               const unsigned short *__restrict__ Wh, const unsigned short *__restrict__ Wl,
                                                               const float *__restrict__ bias, float *__restrict__ C,
@@ -88,21 +104,9 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(const unsigned shor
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
 
-    uint4 ah[2], al[2], wh[2], wl[2];
-    x3_load_stage(Ah, Al, lda, M, m0, 0, tid, ah, al);
-    x3_load_stage(Wh, Wl, ldw, N, n0, 0, tid, wh, wl);
-    x3_store_stage(lds[0][0], lds[0][1], tid, ah, al);
-    x3_store_stage(lds[0][2], lds[0][3], tid, wh, wl);
-    __syncthreads();
-
-    const int nk = K / XBK;
+    const int nk = (K + XBK - 1) / XBK;
     const int li = lane & 31, kb = (lane >> 5) * 16;
-    for (int kt = 0; kt < nk; kt++) {
-        const int cur = kt & 1;
-        if (kt + 1 < nk) {
-            x3_load_stage(Ah, Al, lda, M, m0, (kt + 1) * XBK, tid, ah, al);
-            x3_load_stage(Wh, Wl, ldw, N, n0, (kt + 1) * XBK, tid, wh, wl);
-        }
+    auto compute = [&](int cur) {
 #pragma unroll
         for (int ks = 0; ks < 2; ks++) {
             bf16x8 fah[2], fal[2], fwh[2], fwl[2];
@@ -113,21 +117,64 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(const unsigned shor
                 fwh[i] = x3_frag(lds[cur][2], wn * 64 + i * 32 + li, ks * 32 + kb);
                 fwl[i] = x3_frag(lds[cur][3], wn * 64 + i * 32 + li, ks * 32 + kb);
             }
+            if (ABL & 1) {   // ablation: keep the fragment reads alive, skip the matrix cores
+#pragma unroll
+                for (int i = 0; i < 2; i++) asm volatile("" :: "v"(fah[i]), "v"(fal[i]), "v"(fwh[i]), "v"(fwl[i]));
+                continue;
+            }
 #pragma unroll
             for (int i = 0; i < 2; i++)
 #pragma unroll
-                for (int j = 0; j < 2; j++) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fah[i], fwl[j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fal[i], fwh[j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fah[i], fwh[j], acc[i][j], 0, 0, 0);
-                }
+                for (int j = 0; j < 2; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fah[i], fwl[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 2; i++)
+#pragma unroll
+                for (int j = 0; j < 2; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fal[i], fwh[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 2; i++)
+#pragma unroll
+                for (int j = 0; j < 2; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fah[i], fwh[j], acc[i][j], 0, 0, 0);
         }
-        if (kt + 1 < nk) {
-            x3_store_stage(lds[cur ^ 1][0], lds[cur ^ 1][1], tid, ah, al);
-            x3_store_stage(lds[cur ^ 1][2], lds[cur ^ 1][3], tid, wh, wl);
-        }
-        __syncthreads();
+    };
+
+    // Pipeline over K-tile PAIRS, two register sets (P, Q), loop unrolled by two pairs so both are addressed statically.
+    // Entering the loop body for pair p (tiles 2p, 2p+1): set P holds pair p, LDS stage 0 holds tile 2p.
+    //   issue loads of pair p+1 into Q | compute tile 2p | store tile 2p+1 (P, odd half) -> stage 1 | barrier
+    //   compute tile 2p+1 | store tile 2p+2 (Q, even half) -> stage 0 | barrier            then P <-> Q
+    u32x4 pah[XPL], pal[XPL], pwh[XPL], pwl[XPL], qah[XPL], qal[XPL], qwh[XPL], qwl[XPL];
+    const int npair = (nk + 1) / 2;
+    x3_load_pair(Ah, Al, lda, M, K, m0, 0, tid, pah, pal);
+    x3_load_pair(Wh, Wl, ldw, N, K, n0, 0, tid, pwh, pwl);
+    x3_store_half(lds[0][0], lds[0][1], tid, 0, pah, pal);
+    x3_store_half(lds[0][2], lds[0][3], tid, 0, pwh, pwl);
+    __syncthreads();
+#define X3_PAIR_STEP(P_AH, P_AL, P_WH, P_WL, Q_AH, Q_AL, Q_WH, Q_WL, p)                                   \
+    {                                                                                                     \
+        const bool more = (p) + 1 < npair, odd_tile = 2 * (p) + 1 < nk;                                   \
+        if (more && !(ABL & 2)) {                                                                         \
+            x3_load_pair(Ah, Al, lda, M, K, m0, ((p) + 1) * 2 * XBK, tid, Q_AH, Q_AL);                    \
+            x3_load_pair(Wh, Wl, ldw, N, K, n0, ((p) + 1) * 2 * XBK, tid, Q_WH, Q_WL);                    \
+        }                                                                                                 \
+        compute(0);                                                                                       \
+        if (odd_tile && !(ABL & 4)) {                                                                     \
+            x3_store_half(lds[1][0], lds[1][1], tid, 1, P_AH, P_AL);                                      \
+            x3_store_half(lds[1][2], lds[1][3], tid, 1, P_WH, P_WL);                                      \
+        }                                                                                                 \
+        __syncthreads();                                                                                  \
+        if (odd_tile) {                                                                                   \
+            compute(1);                                                                                   \
+            if (more && !(ABL & 4)) {                                                                     \
+                x3_store_half(lds[0][0], lds[0][1], tid, 0, Q_AH, Q_AL);                                  \
+                x3_store_half(lds[0][2], lds[0][3], tid, 0, Q_WH, Q_WL);                                  \
+            }                                                                                             \
+            __syncthreads();                                                                              \
+        }                                                                                                 \
     }
+    for (int p = 0; p < npair; p += 2) {
+        X3_PAIR_STEP(pah, pal, pwh, pwl, qah, qal, qwh, qwl, p)
+        if (p + 1 < npair) X3_PAIR_STEP(qah, qal, qwh, qwl, pah, pal, pwh, pwl, p + 1)
+    }
+#undef X3_PAIR_STEP
 
     // epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
     const int lh = lane >> 5;
@@ -154,11 +201,128 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(const unsigned shor
         }
 }
 
+// ---- 256x256 tile variant for the large projections: 512 threads = 8 waves (2 x 4), each wave 128x64 = 4x2 MFMA tiles
+// (128 accumulator VGPRs), one workgroup per CU, two waves per SIMD.  A 256x256 tile moves half the bytes per flop of the
+// 128x128 tile through the L2 -> LDS fill path, which is what bounds these GEMMs (see the ablation note above).
+constexpr int YBM = 256, YBN = 256, YPLANE = YBM * XROW;    // 16384 B per plane
+constexpr int YPT = YBM * 4 / 512;                          // 16-byte chunks per thread per plane per K-tile (2)
+
+__device__ __forceinline__ void y3_load(const unsigned short *__restrict__ Ph, const unsigned short *__restrict__ Pl, int ld,
+                                        int rows_total, int K, int row0, int k0, int tid, u32x4 (&rh)[YPT], u32x4 (&rl)[YPT]) {
+#pragma unroll
+    for (int i = 0; i < YPT; i++) {
+        const int q = tid + 512 * i, row = min(row0 + (q >> 2), rows_total - 1), k = k0 + (q & 3) * 8;
+        const size_t off = (size_t)row * ld + min(k, K - 8);
+        const u32x4 vh = *reinterpret_cast<const u32x4 *>(Ph + off), vl = *reinterpret_cast<const u32x4 *>(Pl + off);
+        const u32x4 z = {0u, 0u, 0u, 0u};
+        rh[i] = k < K ? vh : z;
+        rl[i] = k < K ? vl : z;
+    }
+}
+__device__ __forceinline__ void y3_store(unsigned char *ph, unsigned char *pl, int tid, const u32x4 (&rh)[YPT], const u32x4 (&rl)[YPT]) {
+#pragma unroll
+    for (int i = 0; i < YPT; i++) {
+        const int q = tid + 512 * i, row = q >> 2, off = row * XROW + (((q & 3) ^ ((row >> 2) & 3)) << 4);
+        *reinterpret_cast<u32x4 *>(ph + off) = rh[i];
+        *reinterpret_cast<u32x4 *>(pl + off) = rl[i];
+    }
+}
+
+__global__ __launch_bounds__(512, 2) void gemm_bf16x3_256_kernel(const unsigned short *__restrict__ Ah, const unsigned short *__restrict__ Al,
+                                                                  const unsigned short *__restrict__ Wh, const unsigned short *__restrict__ Wl,
+                                                                  const float *__restrict__ bias, float *__restrict__ C, int M, int N, int K,
+                                                                  int lda, int ldw, int ldc, int tiles_n) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char ylds[];   // [2 stages][Ah,Al,Wh,Wl][YPLANE] = 128 KB
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 2, wn = wave & 3;
+    int nwg = gridDim.x, bid = blockIdx.x;
+    int q = nwg >> 3, rem = nwg & 7, xcd = bid & 7;
+    int swz = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + (bid >> 3);
+    const int tm = swz / tiles_n, tn = swz % tiles_n;
+    const int m0 = tm * YBM, n0 = tn * YBN;
+    auto plane = [&](int stage, int p) { return ylds + ((size_t)stage * 4 + p) * YPLANE; };
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+
+    u32x4 ah[YPT], al[YPT], wh[YPT], wl[YPT];
+    const int nk = (K + XBK - 1) / XBK;
+    const int li = lane & 31, kb = (lane >> 5) * 16;
+    y3_load(Ah, Al, lda, M, K, m0, 0, tid, ah, al);
+    y3_load(Wh, Wl, ldw, N, K, n0, 0, tid, wh, wl);
+    y3_store(plane(0, 0), plane(0, 1), tid, ah, al);
+    y3_store(plane(0, 2), plane(0, 3), tid, wh, wl);
+    __syncthreads();
+    for (int kt = 0; kt < nk; kt++) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) {
+            y3_load(Ah, Al, lda, M, K, m0, (kt + 1) * XBK, tid, ah, al);
+            y3_load(Wh, Wl, ldw, N, K, n0, (kt + 1) * XBK, tid, wh, wl);
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++) {
+            bf16x8 fwh[2], fwl[2];
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                fwh[j] = x3_frag(plane(cur, 2), wn * 64 + j * 32 + li, ks * 32 + kb);
+                fwl[j] = x3_frag(plane(cur, 3), wn * 64 + j * 32 + li, ks * 32 + kb);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const bf16x8 fah = x3_frag(plane(cur, 0), wm * 128 + i * 32 + li, ks * 32 + kb);
+                const bf16x8 fal = x3_frag(plane(cur, 1), wm * 128 + i * 32 + li, ks * 32 + kb);
+#pragma unroll
+                for (int j = 0; j < 2; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fah, fwl[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+                for (int j = 0; j < 2; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fal, fwh[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+                for (int j = 0; j < 2; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fah, fwh[j], acc[i][j], 0, 0, 0);
+            }
+        }
+        if (kt + 1 < nk) {
+            y3_store(plane(cur ^ 1, 0), plane(cur ^ 1, 1), tid, ah, al);
+            y3_store(plane(cur ^ 1, 2), plane(cur ^ 1, 3), tid, wh, wl);
+        }
+        __syncthreads();
+    }
+    const int lh = lane >> 5;
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const int col = n0 + wn * 64 + j * 32 + li;
+            if (col >= N) continue;
+            const float bv = bias ? bias[col] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int row = m0 + wm * 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (row < M) C[(size_t)row * ldc + col] = acc[i][j][r] + bv;
+            }
+        }
+}
+
+int init_gemm_attributes() {
+    MDD_HIP_CHECK(hipFuncSetAttribute((const void *)gemm_bf16x3_256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 4 * YPLANE));
+    return MDD_OK;
+}
+
 int launch_gemm_bf16x3(const SplitPtr &A, const SplitPtr &W, const float *bias, float *C, const SplitPtr *Csplit, int M, int N,
                        int K, int lda, int ldw, int ldc, int batch, long sA, long sW, long sC, hipStream_t st) {
-    if (M <= 0 || N <= 0 || K <= 0 || batch <= 0 || K % XBK || lda % 8 || ldw % 8 || sA % 8 || sW % 8) {
+    if (M <= 0 || N <= 0 || K <= 0 || batch <= 0 || K % 8 || lda % 8 || ldw % 8 || sA % 8 || sW % 8) {
         set_error("gemm_bf16x3: bad shape M=%d N=%d K=%d lda=%d ldw=%d", M, N, K, lda, ldw);
         return MDD_ERR_ARG;
+    }
+    if (!Csplit && batch == 1 && M >= 2048 && N >= 512 && getenv("MDD_GEMM256")) {   // opt-in 256x256 tiles (measured slower: 3.28 vs 2.95 ms)
+        const int tm = (M + YBM - 1) / YBM, tn = (N + YBN - 1) / YBN;
+        hipLaunchKernelGGL(gemm_bf16x3_256_kernel, dim3(tm * tn), dim3(512), 2 * 4 * YPLANE, st, A.hi, A.lo, W.hi, W.lo, bias, C, M, N, K,
+                           lda, ldw, ldc, tn);
+        MDD_LAUNCH_CHECK();
+        return MDD_OK;
     }
     const int tiles_m = (M + XBM - 1) / XBM, tiles_n = (N + XBN - 1) / XBN;
     dim3 grid(tiles_m * tiles_n, 1, batch), block(256);
@@ -171,6 +335,34 @@ int launch_gemm_bf16x3(const SplitPtr &A, const SplitPtr &W, const float *bias, 
     MDD_LAUNCH_CHECK();
     return MDD_OK;
 }
+
+}  // namespace mdd
+// Diagnostic hook (not part of the product ABI): time the GEMM kernel and its ablations.
+extern "C" int mdd_diag_gemm(int M, int N, int K, int abl, int iters, float *ms_out) {
+    using namespace mdd;
+    unsigned short *A = nullptr, *W = nullptr; float *C = nullptr;
+    MDD_HIP_CHECK(hipMalloc((void **)&A, (size_t)2 * M * K * 2));
+    MDD_HIP_CHECK(hipMalloc((void **)&W, (size_t)2 * N * K * 2));
+    MDD_HIP_CHECK(hipMalloc((void **)&C, (size_t)M * N * 4));
+    MDD_HIP_CHECK(hipMemset(A, 0x3c, (size_t)2 * M * K * 2));
+    MDD_HIP_CHECK(hipMemset(W, 0x3b, (size_t)2 * N * K * 2));
+    const int tiles_m = (M + XBM - 1) / XBM, tiles_n = (N + XBN - 1) / XBN;
+    dim3 grid(tiles_m * tiles_n, 1, 1), block(256);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int it = -1; it < iters; it++) {
+        if (it == 0) hipEventRecord(e0, nullptr);
+#define LAUNCH_ABL(X) hipLaunchKernelGGL((gemm_bf16x3_kernel<0, X>), grid, block, 0, nullptr, A, A + (size_t)M * K, W, W + (size_t)N * K, (const float *)nullptr, C, \
+                                          (unsigned short *)nullptr, (unsigned short *)nullptr, M, N, K, K, K, N, 0l, 0l, 0l, tiles_n)
+        switch (abl) { case 0: LAUNCH_ABL(0); break; case 1: LAUNCH_ABL(1); break; case 2: LAUNCH_ABL(2); break; case 3: LAUNCH_ABL(3); break;
+                       case 6: LAUNCH_ABL(6); break; default: LAUNCH_ABL(7); }
+#undef LAUNCH_ABL
+    }
+    hipEventRecord(e1, nullptr); hipEventSynchronize(e1);
+    float t = 0; hipEventElapsedTime(&t, e0, e1); *ms_out = t / iters;
+    hipFree(A); hipFree(W); hipFree(C); hipEventDestroy(e0); hipEventDestroy(e1);
+    return MDD_OK;
+}
+namespace mdd {
 
 // fp32 [n] -> hi/lo planes (used for weights at load time and by the tap / test helpers)
 __global__ void split_kernel(const float *__restrict__ x, size_t n, unsigned short *__restrict__ hi, unsigned short *__restrict__ lo) {

@@ -37,6 +37,7 @@ int launch_gemm_nt(const float *A, const float *W, const float *bias, float *C, 
 // split-bf16 tensor when Csplit != nullptr.  K % 32 == 0, ld* % 8 == 0.
 int launch_gemm_bf16x3(const SplitPtr &A, const SplitPtr &W, const float *bias, float *C, const SplitPtr *Csplit, int M, int N,
                        int K, int lda, int ldw, int ldc, int batch, long sA, long sW, long sC, hipStream_t st);
+int init_gemm_attributes();
 int launch_split(const float *x, size_t n, const SplitPtr &out, hipStream_t st);
 int launch_unsplit(const SplitPtr &in, size_t n, float *x, hipStream_t st);
 
