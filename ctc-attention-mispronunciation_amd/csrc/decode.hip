@@ -382,6 +382,271 @@ __global__ __launch_bounds__(64) void beam_kernel(const double *__restrict__ lpw
     }
 }
 
+// ---- pass 2, fast path (beam <= 16, C <= 64): same algorithm, restructured for a single wave's latency.
+// A lone wave pays ~100 cycles for every dependent LDS round trip, so the work is arranged in unrolled phases whose
+// loads are all independent: slots are dealt to lanes round-robin (slot = lane + 64 i, coordinates precomputed once),
+// the beam state is a structure of arrays, candidate operands are gathered before anything is stored, the top-`beam`
+// selection reads each lane's slots into registers once and then uses wave ballots / v_readlane only:
+//   lane maxima -> rank by v_readlane broadcast -> theta0 (keep-th largest lane maximum; because slots are dealt
+//   round-robin the true winners sit in different lanes and theta0 is tight) -> ballot compaction of the ~10-20
+//   candidates >= theta0 -> rank counting among those (rank < keep IS the output position).
+constexpr int FB = 16;   // max beams on the fast path
+
+template <int NS>
+__global__ __launch_bounds__(64) void beam_fast_kernel(const double *__restrict__ lpw, const unsigned char *__restrict__ flags,
+                                                       int T, int B, int C, const int32_t *__restrict__ len, int beam, int blank,
+                                                       const double *__restrict__ lm, double alpha, int32_t *__restrict__ ids,
+                                                       int32_t *__restrict__ nids, int32_t *__restrict__ status,
+                                                       double *__restrict__ score, int Tcap) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
+    const int C1 = C + 1;
+    double *tot = reinterpret_cast<double *>(sm);                     // [NS*64]
+    double *lmt = tot + NS * 64;                                       // [C1*C1]
+    double *cl_v = lmt + C1 * C1;                                      // [NS*64] compacted candidates: value,
+    int *cl_o = reinterpret_cast<int *>(cl_v + NS * 64);               //   insertion order,
+    int *cl_x = cl_o + NS * 64;                                        //   slot index
+    unsigned char *fl = reinterpret_cast<unsigned char *>(cl_x + NS * 64);
+    unsigned char *pref = fl + Tcap;
+    __shared__ double lp[64];
+    __shared__ double m_T[2][FB], m_NB[2][FB], m_B[2][FB];
+    __shared__ unsigned long long m_hash[2][FB], m_phash[2][FB];
+    __shared__ int m_len[2][FB], m_last[2][FB];
+    __shared__ double cNB[FB], cB[FB], cT[FB], sel_v[FB];
+    __shared__ int parent[FB], mslot[FB], sel_x[FB];
+
+    const int b = blockIdx.x, lane = threadIdx.x;
+    int cur = 0, nb = 1, err = 0;
+    if (lane == 0) {
+        m_T[0][0] = 0.0; m_B[0][0] = 0.0; m_NB[0][0] = LOG_ZERO; m_len[0][0] = 0; m_last[0][0] = -1;
+        m_hash[0][0] = 0x243F6A8885A308D3ull; m_phash[0][0] = 0;
+    }
+    for (int i = lane; i < C1 * C1; i += 64) lmt[i] = lm[i];
+    int tl = len[b];
+    tl = tl < 0 ? 0 : (tl > T ? T : tl);
+    for (int i = lane; i < tl; i += 64) fl[i] = flags[(size_t)i * B + b];
+    // slot coordinates of this lane (constant over the whole utterance): slot = lane + 64 i = r*C + k
+    int sr[NS], sk[NS], so[NS];
+#pragma unroll
+    for (int i = 0; i < NS; i++) {
+        const int idx = lane + 64 * i;
+        sr[i] = idx / C; sk[i] = idx - sr[i] * C;
+        so[i] = sr[i] * C + (sk[i] == blank ? 0 : (sk[i] < blank ? sk[i] + 1 : sk[i]));   // insertion order of the slot
+    }
+    const float invC = 1.0f / (float)C;
+    __syncthreads();
+
+    int t = 0;
+    while (t < tl && !(fl[t] & 1)) t++;
+    double pre = (t < tl && lane < C) ? lpw[((size_t)t * B + b) * C + lane] : 0.0;
+    while (t < tl) {
+        const bool rep_ok = (fl[t] & 2) != 0;
+        if (lane < C) lp[lane] = pre;
+        int tn = t + 1;
+        while (tn < tl && !(fl[tn] & 1)) tn++;
+        pre = (tn < tl && lane < C) ? lpw[((size_t)tn * B + b) * C + lane] : 0.0;
+        __syncthreads();
+        unsigned char *pcur = pref + (size_t)cur * beam * Tcap, *pnext = pref + (size_t)(cur ^ 1) * beam * Tcap;
+        const int nslot = nb * C;
+
+        // ---- candidate scores: gather every operand first (independent LDS reads), then store
+        int first_err_ord = 0x7fffffff, first_err = 0;
+        double val[NS];
+#pragma unroll
+        for (int i = 0; i < NS; i++) {
+            const int r = min(sr[i], nb - 1), k = sk[i];
+            const int ylen = m_len[cur][r], ylast = m_last[cur][r];
+            const double yB = m_B[cur][r], yT = m_T[cur][r];
+            const double lmv = lmt[(ylen ? ylast : C) * C1 + k];   // consulted even when alpha == 0 (BeamSearch.py:57-60)
+            const double lk = lp[k];
+            const bool live = lane + 64 * i < nslot && k != blank;
+            if (live) {
+                const int ord = sr[i] * C1 + 1 + k;
+                if (lmv != lmv) { if (ord < first_err_ord) { first_err_ord = ord; first_err = MDD_BEAM_KEY_ERROR; } }
+                else if (lk == -INFINITY) { if (ord < first_err_ord) { first_err_ord = ord; first_err = MDD_BEAM_VALUE_ERROR; } }
+            }
+            const double base = (ylen && ylast == k && rep_ok) ? yB : yT;   // :63-66
+            val[i] = live ? lk + lmv * alpha + base : -INFINITY;
+        }
+#pragma unroll
+        for (int i = 0; i < NS; i++)
+            if (sk[i] != blank || lane + 64 * i >= nslot) tot[lane + 64 * i] = val[i];   // copy slots are written below
+        // ---- copy path of beam `lane` (:101-113) and its parent candidate
+        if (lane < nb) {
+            const int ylen = m_len[cur][lane], ylast = m_last[cur][lane];
+            double pnb = LOG_ZERO;
+            const double lpb = lp[blank];
+            bool bad = (lpb == -INFINITY);
+            if (ylen > 0) { const double lpl = lp[ylast]; pnb = m_NB[cur][lane] + lpl; bad = bad || (lpl == -INFINITY); }
+            const double pb = m_T[cur][lane] + lpb;
+            if (bad) { const int ord = lane * C1; if (ord < first_err_ord) { first_err_ord = ord; first_err = MDD_BEAM_VALUE_ERROR; } }
+            cNB[lane] = pnb; cB[lane] = pb;
+            const double tc = log_add_prob(pb, pnb);
+            cT[lane] = tc;
+            tot[lane * C + blank] = tc;
+            int par = -1;
+            const unsigned long long myph = m_phash[cur][lane];
+#pragma unroll
+            for (int q = 0; q < FB; q++)
+                if (q < nb && par < 0 && q != lane && ylen > 0 && m_len[cur][q] == ylen - 1 && m_hash[cur][q] == myph) par = q;
+            parent[lane] = par;
+            mslot[lane] = -1;
+        }
+        // verify the content of every hash match with the whole wave (never merge on a hash collision)
+        for (int a = 0; a < nb; a++) {
+            const int q = parent[a];
+            if (q < 0) continue;
+            const int ln = m_len[cur][q];
+            const unsigned int *wa = reinterpret_cast<const unsigned int *>(pcur + (size_t)a * Tcap);
+            const unsigned int *wq = reinterpret_cast<const unsigned int *>(pcur + (size_t)q * Tcap);
+            bool neq = false;
+            for (int j = lane; j * 4 < ln; j += 64) {
+                unsigned int x = wa[j] ^ wq[j];
+                const int rem = ln - j * 4;
+                if (rem < 4) x &= (1u << (8 * rem)) - 1u;
+                neq = neq || (x != 0);
+            }
+            if (__any(neq) && lane == 0) parent[a] = -1;
+        }
+        {   // first error in the reference's execution order wins
+            int eo = first_err_ord;
+            for (int o = 32; o > 0; o >>= 1) eo = min(eo, __shfl_xor(eo, o));
+            if (eo != 0x7fffffff) {
+                const unsigned long long who = __ballot(first_err_ord == eo);
+                err = __shfl(first_err, __ffsll((long long)who) - 1);
+                break;
+            }
+        }
+        __syncthreads();
+        // ---- merges (see beam_kernel)
+        int nmerge = 0;
+        if (lane < nb && parent[lane] >= 0) {
+            const int a = lane, q = parent[a], e = q * C + m_last[cur][a];
+            const double pr = tot[e];
+            if (q < a) {
+                cNB[a] = log_add_prob(pr, cNB[a]);
+                cT[a] = log_add_prob(pr, cT[a]);
+                tot[e] = cT[a];
+                tot[a * C + blank] = -INFINITY;
+                mslot[a] = e;
+            } else {
+                cNB[a] = log_add_prob(cNB[a], pr);
+                cT[a] = log_add_prob(cT[a], pr);
+                tot[a * C + blank] = cT[a];
+                tot[e] = -INFINITY;
+            }
+            nmerge = 1;
+        }
+        nmerge = __popcll(__ballot(nmerge != 0));
+        __syncthreads();
+        // ---- top-`keep` selection
+        const int ncand = nslot - nmerge;
+        const int keep = ncand < beam ? ncand : beam;
+        double tv[NS];
+#pragma unroll
+        for (int i = 0; i < NS; i++) tv[i] = tot[lane + 64 * i];     // slots >= nslot hold -inf
+        double lmax = tv[0];
+#pragma unroll
+        for (int i = 1; i < NS; i++) lmax = fmax(lmax, tv[i]);
+        int rk = 0;
+        {
+            const int lo = __double2loint(lmax), hi = __double2hiint(lmax);
+#pragma unroll 16
+            for (int j = 0; j < 64; j++) {
+                const double sj = __hiloint2double(__builtin_amdgcn_readlane(hi, j), __builtin_amdgcn_readlane(lo, j));
+                rk += (sj > lmax || (sj == lmax && j < lane)) ? 1 : 0;
+            }
+        }
+        const unsigned long long mk = __ballot(rk == keep - 1);
+        const int srcl = __ffsll((long long)mk) - 1;
+        const double theta0 = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(lmax), srcl),
+                                               __builtin_amdgcn_readlane(__double2loint(lmax), srcl));
+        int nl = 0;
+        const unsigned long long lt = (1ull << lane) - 1ull;
+#pragma unroll
+        for (int i = 0; i < NS; i++) {
+            const bool pred = tv[i] >= theta0 && lane + 64 * i < nslot;
+            const unsigned long long msk = __ballot(pred);
+            if (pred) {
+                const int pos = nl + __popcll(msk & lt);
+                cl_v[pos] = tv[i]; cl_o[pos] = so[i]; cl_x[pos] = lane + 64 * i;
+            }
+            nl += __popcll(msk);
+        }
+        __syncthreads();
+        for (int e = lane; e < nl; e += 64) {
+            const double v = cl_v[e];
+            const int o = cl_o[e];
+            int rank = 0;
+#pragma unroll 4
+            for (int f = 0; f < nl; f++) {
+                const double vf = cl_v[f];
+                const int of = cl_o[f];
+                rank += (vf > v || (vf == v && of < o)) ? 1 : 0;
+            }
+            if (rank < keep) { sel_v[rank] = v; sel_x[rank] = cl_x[e]; }
+        }
+        __syncthreads();
+        // ---- materialise the new beams
+        const int nxt = cur ^ 1;
+        if (lane < keep) {
+            const int idx = sel_x[lane];
+            const int r = (int)(((float)idx + 0.5f) * invC), k = idx - r * C;
+            const double v = sel_v[lane];
+            if (k == blank) {
+                m_T[nxt][lane] = v; m_NB[nxt][lane] = cNB[r]; m_B[nxt][lane] = cB[r];
+                m_len[nxt][lane] = m_len[cur][r]; m_last[nxt][lane] = m_last[cur][r];
+                m_hash[nxt][lane] = m_hash[cur][r]; m_phash[nxt][lane] = m_phash[cur][r];
+            } else {
+                double nbv = v, bv = LOG_ZERO;
+#pragma unroll
+                for (int a = 0; a < FB; a++)
+                    if (a < nb && mslot[a] == idx) { nbv = cNB[a]; bv = cB[a]; }
+                const unsigned long long h = m_hash[cur][r];
+                m_T[nxt][lane] = v; m_NB[nxt][lane] = nbv; m_B[nxt][lane] = bv;
+                m_len[nxt][lane] = m_len[cur][r] + 1; m_last[nxt][lane] = k;
+                m_phash[nxt][lane] = h; m_hash[nxt][lane] = h * 0x9E3779B97F4A7C15ull + (unsigned long long)(k + 1);
+            }
+        }
+        for (int i = 0; i < keep; i++) {
+            const int idx = sel_x[i];
+            const int r = (int)(((float)idx + 0.5f) * invC), k = idx - r * C;
+            const int ln = m_len[cur][r];
+            const unsigned int *src = reinterpret_cast<const unsigned int *>(pcur + (size_t)r * Tcap);
+            unsigned int *dst = reinterpret_cast<unsigned int *>(pnext + (size_t)i * Tcap);
+            for (int j = lane; j * 4 < ln; j += 64) dst[j] = src[j];
+            __builtin_amdgcn_wave_barrier();
+            if (k != blank && lane == 0) reinterpret_cast<unsigned char *>(dst)[ln] = (unsigned char)k;
+        }
+        __syncthreads();
+        cur = nxt;
+        nb = keep;
+        t = tn;
+    }
+    __syncthreads();
+    if (lane == 0) {   // final: EOS LM term, length normalisation, first maximum (:130-148)
+        int best = -1;
+        double bestv = 0.0;
+        for (int r = 0; r < nb && !err; r++) {
+            const int ylen = m_len[cur][r];
+            if (ylen == 0) { err = MDD_BEAM_INDEX_ERROR; break; }
+            const double v = lmt[m_last[cur][r] * C1 + C];
+            if (v != v) { err = MDD_BEAM_KEY_ERROR; break; }
+            double pr = log_add_prob(LOG_ZERO, m_T[cur][r] + v * alpha);
+            pr = pr * (1.0 / (double)(ylen ? ylen : 1));
+            if (best < 0 || pr > bestv) { best = r; bestv = pr; }
+        }
+        status[b] = err;
+        int n = 0;
+        if (!err && best >= 0) {
+            n = m_len[cur][best];
+            const unsigned char *src = pref + (size_t)cur * beam * Tcap + (size_t)best * Tcap;
+            for (int j = 0; j < n; j++) ids[(size_t)b * T + j] = src[j];
+        }
+        nids[b] = n;
+        if (score) score[b] = err ? __builtin_nan("") : bestv;
+    }
+}
+
 }  // namespace mdd
 
 extern "C" int mdd_greedy(const float *logp_dev, int32_t T, int32_t B, int32_t C, const int32_t *len_dev, int32_t blank,
@@ -426,6 +691,20 @@ extern "C" int mdd_beam(const float *logp_dev, int32_t T, int32_t B, int32_t C, 
     int grid = (int)((n + 255) / 256);
     if (grid > 2048) grid = 2048;
     hipLaunchKernelGGL(beam_prep_kernel, dim3(grid), dim3(256), 0, st, logp_dev, T, B, C, blank, lpw, flags);
+    const int nslots = beam * C;
+    if (beam <= FB && C <= 64 && nslots <= 1024 && !getenv("MDD_BEAM_GENERIC")) {
+        const int NS = nslots <= 512 ? 8 : 16;
+        const size_t fs = (size_t)NS * 64 * (8 + 8 + 4 + 4) + sizeof(double) * (size_t)(C + 1) * (C + 1) + (size_t)(2 * beam + 1) * Tcap + 16;
+        static bool fattr = false;
+        if (!fattr) {
+            MDD_HIP_CHECK(hipFuncSetAttribute((const void *)beam_fast_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024));
+            MDD_HIP_CHECK(hipFuncSetAttribute((const void *)beam_fast_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024));
+            fattr = true;
+        }
+        if (fs > 120 * 1024) { (void)hipFreeAsync(lpw, st); set_error("mdd_beam: T too long for LDS (%zu B)", fs); return MDD_ERR_ARG; }
+        if (NS == 8) hipLaunchKernelGGL(beam_fast_kernel<8>, dim3(B), dim3(64), fs, st, lpw, flags, T, B, C, len_dev, beam, blank, lm_dev, lm_alpha, ids_dev, nids_dev, status_dev, score_dev, Tcap);
+        else hipLaunchKernelGGL(beam_fast_kernel<16>, dim3(B), dim3(64), fs, st, lpw, flags, T, B, C, len_dev, beam, blank, lm_dev, lm_alpha, ids_dev, nids_dev, status_dev, score_dev, Tcap);
+    } else
     hipLaunchKernelGGL(beam_kernel, dim3(B), dim3(64), smem, st, lpw, flags, T, B, C, len_dev, beam, blank, lm_dev, lm_alpha,
                        ids_dev, nids_dev, status_dev, score_dev, Tcap, lm_in_lds, getenv("MDD_BEAM_SKIP") ? atoi(getenv("MDD_BEAM_SKIP")) : 0,
                        getenv("MDD_BEAM_DBG") ? reinterpret_cast<long long *>(score_dev) + B : nullptr);
