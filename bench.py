@@ -43,6 +43,7 @@ def parse():
     ap.add_argument("--fuse", type=int, default=4, help="reference-sized batches carried by one launch sequence")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true", help="skip the posterior all-gather at N>1")
+    ap.add_argument("--no-roofline", action="store_true", help="skip the stage-replay pass (for clean traces)")
     return ap.parse_args()
 
 
@@ -173,7 +174,7 @@ def main():
     # ---- roofline of the dominant kernel, measured with HIP events on the launch stream (stage replay)
     roof = None
     stages = None
-    if rank == 0:
+    if rank == 0 and not args.no_roofline:
         x = stack_features(raw)
         torch.cuda.synchronize()
         reps = [model.profile(x, x1) for _ in range(3)]

@@ -197,6 +197,17 @@ __global__ __launch_bounds__(256, 2) void conv_fused_kernel(const float *__restr
         bwh[i] = *reinterpret_cast<const bf16x8 *>(w1h + (size_t)li * 288 + kb * 16 + half * 8);
         bwl[i] = *reinterpret_cast<const bf16x8 *>(w1l + (size_t)li * 288 + kb * 16 + half * 8);
     }
+    // conv0 weights as resident A fragments: lane (channel li, k-slice half): taps half*8 .. half*8+7 (taps >= 9 are zero)
+    bf16x8 w0h, w0l;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const int tap = half * 8 + j;
+        const float wv = tap < 9 ? w0[li * 9 + tap] : 0.f;
+        w0h[j] = (__bf16)wv; w0l[j] = (__bf16)(wv - (float)w0h[j]);
+    }
+    float c0s[16], c0h[16];      // folded BN of the 16 channels this lane receives in D: reg q -> channel (q&3) + 8*(q>>2) + 4*half
+#pragma unroll
+    for (int q = 0; q < 16; q++) { const int ch = (q & 3) + 8 * (q >> 2) + 4 * half; c0s[q] = sc0[ch]; c0h[q] = sh0[ch]; }
     // zero the left pad column of the conv0 tile once (wcol = -1)
     for (int i = tid; i < 3 * 2 * CF_COLB / 4; i += 256) {
         const int r = i / (2 * CF_COLB / 4), rem = i - r * (2 * CF_COLB / 4);
@@ -212,38 +223,45 @@ __global__ __launch_bounds__(256, 2) void conv_fused_kernel(const float *__restr
             xs[i] = (ti >= 0 && ti < T && c >= 0 && c < F) ? x[((size_t)b * T + ti) * F + c] : 0.f;
         }
         __syncthreads();
-        // ---- conv0 + BN + ReLU -> bf16 hi/lo, layout [r][wcol+1][ci]
-        for (int p = tid; p < 3 * W1; p += 256) {
-            const int r = p / W1, wc = p - r * W1, ti = 2 * tp - 1 + r;
-            const bool rowok = ti >= 0 && ti < T;
-            float in[9];
+        // ---- conv0 on the matrix cores: D[ch, pos] = W0[ch, k] . P[k, pos], k = 9 taps padded to 16 (one MFMA k-step),
+        // bf16x3.  A = weights (resident fragments), B = the 3x3 patch of each of the 3*122 = 366 positions (12 tiles of
+        // 32, 3 per wave), built from the fp32 x tile.  D puts the position on the lane and 16 channels in the registers
+        // (4 groups of 4 consecutive channels), exactly the [r][wcol+1][ci] rows conv1 reads: 8-byte LDS stores.
+        for (int pt = wave; pt < 12; pt += 4) {
+            const int p = pt * 32 + li, pc = min(p, 3 * W1 - 1);
+            const int r = pc / W1, wc = pc - r * W1, ti = 2 * tp - 1 + r;
+            const bool rowok = ti >= 0 && ti < T && p < 3 * W1;
+            float v[8];
 #pragma unroll
-            for (int kh = 0; kh < 3; kh++)
+            for (int j = 0; j < 8; j++) {
+                const int tap = half * 8 + j, kh = tap / 3, kw = tap - kh * 3;           // taps 9..15 are padding
+                v[j] = (tap < 9) ? xs[(r + kh) * CF_XLD + 2 * wc + kw] : 0.f;
+            }
+            bf16x8 bh, bl;
 #pragma unroll
-                for (int kw = 0; kw < 3; kw++) in[kh * 3 + kw] = xs[(r + kh) * CF_XLD + 2 * wc + kw];   // x col 2wc+kw-1, +1 pad
-            unsigned char *dh = yh + (r * CF_NCOL + wc + 1) * CF_COLB, *dl = yl + (r * CF_NCOL + wc + 1) * CF_COLB;
+            for (int j = 0; j < 8; j++) { bh[j] = (__bf16)v[j]; bl[j] = (__bf16)(v[j] - (float)bh[j]); }
+            f32x16 d;
 #pragma unroll
-            for (int cg = 0; cg < 4; cg++) {
-                unsigned int hw[4], lw[4];
+            for (int q = 0; q < 16; q++) d[q] = 0.f;
+            d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0h, bl, d, 0, 0, 0);
+            d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0l, bh, d, 0, 0, 0);
+            d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0h, bh, d, 0, 0, 0);
+            if (p < 3 * W1) {
+                unsigned char *dh = yh + (r * CF_NCOL + wc + 1) * CF_COLB, *dl = yl + (r * CF_NCOL + wc + 1) * CF_COLB;
 #pragma unroll
-                for (int cp = 0; cp < 4; cp++) {
-                    float v[2];
+                for (int g = 0; g < 4; g++) {      // registers 4g..4g+3 = channels 8g + 4*half + 0..3
+                    unsigned short hb[4], lb[4];
 #pragma unroll
-                    for (int e = 0; e < 2; e++) {
-                        const int c = cg * 8 + cp * 2 + e;
-                        float acc = 0.f;
-#pragma unroll
-                        for (int j = 0; j < 9; j++) acc = fmaf(in[j], w0[c * 9 + j], acc);
-                        acc = acc * sc0[c] + sh0[c];
-                        v[e] = (rowok && acc > 0.f) ? acc : 0.f;
+                    for (int e = 0; e < 4; e++) {
+                        float a = d[4 * g + e] * c0s[4 * g + e] + c0h[4 * g + e];
+                        a = (rowok && a > 0.f) ? a : 0.f;
+                        __bf16 h = (__bf16)a, l = (__bf16)(a - (float)h);
+                        hb[e] = *reinterpret_cast<unsigned short *>(&h); lb[e] = *reinterpret_cast<unsigned short *>(&l);
                     }
-                    __bf16 h0 = (__bf16)v[0], h1 = (__bf16)v[1];
-                    __bf16 l0 = (__bf16)(v[0] - (float)h0), l1 = (__bf16)(v[1] - (float)h1);
-                    hw[cp] = (unsigned int)*reinterpret_cast<unsigned short *>(&h0) | ((unsigned int)*reinterpret_cast<unsigned short *>(&h1) << 16);
-                    lw[cp] = (unsigned int)*reinterpret_cast<unsigned short *>(&l0) | ((unsigned int)*reinterpret_cast<unsigned short *>(&l1) << 16);
+                    const int cb = (8 * g + 4 * half) * 2;
+                    *reinterpret_cast<uint2 *>(dh + cb) = make_uint2(hb[0] | ((unsigned)hb[1] << 16), hb[2] | ((unsigned)hb[3] << 16));
+                    *reinterpret_cast<uint2 *>(dl + cb) = make_uint2(lb[0] | ((unsigned)lb[1] << 16), lb[2] | ((unsigned)lb[3] << 16));
                 }
-                *reinterpret_cast<u32x4 *>(dh + cg * 16) = (u32x4){hw[0], hw[1], hw[2], hw[3]};
-                *reinterpret_cast<u32x4 *>(dl + cg * 16) = (u32x4){lw[0], lw[1], lw[2], lw[3]};
             }
         }
         __syncthreads();
