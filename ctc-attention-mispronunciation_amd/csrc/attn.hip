@@ -164,15 +164,21 @@ __global__ __launch_bounds__(256) void attn_tail_mfma_kernel(const float *__rest
     }
     __syncthreads();
 
-    // 2. ctx tiles: A = attw[row li][k], B = V[k = l][col d]
+    // 2. ctx tiles: A = attw[row li][k], B = V[k = l][col d].  All V values of a tile are requested before the first MFMA
+    //    (a lone dependent global load per k-step cost ~500 cycles each: 120 of them per wave dominated this kernel).
     for (int nt = wave; nt * 16 < H2; nt += 4) {
         const int d = nt * 16 + li;
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        for (int ks = 0; ks < LA; ks += 4) {
-            const int l = ks + kq;
-            const float a = attw[li * LA + l];
-            const float v = V[((size_t)(l < L ? l : L - 1) * B + b) * H2 + d];   // attw is 0 for l >= L
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, v, acc, 0, 0, 0);
+        for (int k0 = 0; k0 < LA; k0 += 64) {
+            float vv[16];
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                const int l = k0 + 4 * i + kq;
+                vv[i] = (k0 + 4 * i < LA) ? V[((size_t)(l < L ? l : L - 1) * B + b) * H2 + d] : 0.f;   // attw is 0 for l >= L
+            }
+#pragma unroll
+            for (int i = 0; i < 16; i++)
+                if (k0 + 4 * i < LA) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(attw[li * LA + k0 + 4 * i + kq], vv[i], acc, 0, 0, 0);
         }
         const float sc = fscale[H2 + d], hc = fshift[H2 + d];
 #pragma unroll
@@ -186,22 +192,29 @@ __global__ __launch_bounds__(256) void attn_tail_mfma_kernel(const float *__rest
         const float4 *wp = reinterpret_cast<const float4 *>(wfcp) + (size_t)wave * 3 * J * 64 + lane;
         const float *yr = y + li * LDY + wave * (D2 / 4) + 4 * kq;
         f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0;
-#pragma unroll 4
-        for (int j = 0; j < J; j++) {
-            const float4 y4 = *reinterpret_cast<const float4 *>(yr + 16 * j);
-            const float4 w0 = wp[(0 * J + j) * 64], w1 = wp[(1 * J + j) * 64], w2 = wp[(2 * J + j) * 64];
-            a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(y4.x, w0.x, a0, 0, 0, 0);
-            a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(y4.x, w1.x, a1, 0, 0, 0);
-            a2 = __builtin_amdgcn_mfma_f32_16x16x4f32(y4.x, w2.x, a2, 0, 0, 0);
-            a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(y4.y, w0.y, a0, 0, 0, 0);
-            a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(y4.y, w1.y, a1, 0, 0, 0);
-            a2 = __builtin_amdgcn_mfma_f32_16x16x4f32(y4.y, w2.y, a2, 0, 0, 0);
-            a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(y4.z, w0.z, a0, 0, 0, 0);
-            a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(y4.z, w1.z, a1, 0, 0, 0);
-            a2 = __builtin_amdgcn_mfma_f32_16x16x4f32(y4.z, w2.z, a2, 0, 0, 0);
-            a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(y4.w, w0.w, a0, 0, 0, 0);
-            a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(y4.w, w1.w, a1, 0, 0, 0);
-            a2 = __builtin_amdgcn_mfma_f32_16x16x4f32(y4.w, w2.w, a2, 0, 0, 0);
+        for (int j0 = 0; j0 < J; j0 += 4) {      // J % 4 == 0 (D2 % 256 == 0 for H in {256, 384})
+            float4 y4[4], w0[4], w1[4], w2[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int j = j0 + u;
+                y4[u] = *reinterpret_cast<const float4 *>(yr + 16 * j);
+                w0[u] = wp[(0 * J + j) * 64]; w1[u] = wp[(1 * J + j) * 64]; w2[u] = wp[(2 * J + j) * 64];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(y4[u].x, w0[u].x, a0, 0, 0, 0);
+                a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(y4[u].x, w1[u].x, a1, 0, 0, 0);
+                a2 = __builtin_amdgcn_mfma_f32_16x16x4f32(y4[u].x, w2[u].x, a2, 0, 0, 0);
+                a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(y4[u].y, w0[u].y, a0, 0, 0, 0);
+                a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(y4[u].y, w1[u].y, a1, 0, 0, 0);
+                a2 = __builtin_amdgcn_mfma_f32_16x16x4f32(y4[u].y, w2[u].y, a2, 0, 0, 0);
+                a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(y4[u].z, w0[u].z, a0, 0, 0, 0);
+                a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(y4[u].z, w1[u].z, a1, 0, 0, 0);
+                a2 = __builtin_amdgcn_mfma_f32_16x16x4f32(y4[u].z, w2[u].z, a2, 0, 0, 0);
+                a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(y4[u].w, w0[u].w, a0, 0, 0, 0);
+                a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(y4[u].w, w1[u].w, a1, 0, 0, 0);
+                a2 = __builtin_amdgcn_mfma_f32_16x16x4f32(y4[u].w, w2[u].w, a2, 0, 0, 0);
+            }
         }
         float *pw = part + wave * 16 * 48;
 #pragma unroll
@@ -228,7 +241,7 @@ __global__ __launch_bounds__(256) void attn_tail_mfma_kernel(const float *__rest
 
 int launch_attn_tail(const float *S, int Lp, const float *X, const float *V, const float *fscale, const float *fshift,
                      const float *wfc, const float *wfcp, float *logp, int Tp, int B, int L, int H2, int C, hipStream_t st) {
-    if (wfcp && (2 * H2) % 64 == 0 && C <= 48) {
+    if (wfcp && (2 * H2) % 256 == 0 && C <= 48) {
         const int D2 = 2 * H2, LA = (L + 3) & ~3;
         size_t smem = sizeof(float) * ((size_t)16 * LA + (size_t)16 * (D2 + 4) + 4 * 16 * 48);
         if (smem > 160 * 1024) { set_error("attn_tail: L=%d too long for the LDS tile (%zu B)", L, smem); return MDD_ERR_ARG; }
