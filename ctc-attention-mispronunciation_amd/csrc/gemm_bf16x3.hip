@@ -340,12 +340,14 @@ int launch_gemm_bf16x3(const SplitPtr &A, const SplitPtr &W, const float *bias, 
 // Diagnostic hook (not part of the product ABI): time the GEMM kernel and its ablations.
 extern "C" int mdd_diag_gemm(int M, int N, int K, int abl, int iters, float *ms_out) {
     using namespace mdd;
+    const int pad = getenv("MDD_DIAG_PAD") ? atoi(getenv("MDD_DIAG_PAD")) : 0;   // extra elements per row (leading-dimension experiment)
+    const int LD = K + pad;
     unsigned short *A = nullptr, *W = nullptr; float *C = nullptr;
-    MDD_HIP_CHECK(hipMalloc((void **)&A, (size_t)2 * M * K * 2));
-    MDD_HIP_CHECK(hipMalloc((void **)&W, (size_t)2 * N * K * 2));
+    MDD_HIP_CHECK(hipMalloc((void **)&A, (size_t)2 * M * LD * 2));
+    MDD_HIP_CHECK(hipMalloc((void **)&W, (size_t)2 * N * LD * 2));
     MDD_HIP_CHECK(hipMalloc((void **)&C, (size_t)M * N * 4));
-    MDD_HIP_CHECK(hipMemset(A, 0x3c, (size_t)2 * M * K * 2));
-    MDD_HIP_CHECK(hipMemset(W, 0x3b, (size_t)2 * N * K * 2));
+    MDD_HIP_CHECK(hipMemset(A, 0x3c, (size_t)2 * M * LD * 2));
+    MDD_HIP_CHECK(hipMemset(W, 0x3b, (size_t)2 * N * LD * 2));
     const int tiles_m = (M + XBM - 1) / XBM, tiles_n = (N + XBN - 1) / XBN;
     dim3 grid(tiles_m * tiles_n, 1, 1), block(256);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);

@@ -235,3 +235,74 @@ def test_persistent_lstm_equals_step_kernels_bitwise(monkeypatch):
     for _ in range(3):
         got = m.forward(_cuda(x), _cuda(x1), sync_errors=True).cpu().numpy()
         np.testing.assert_array_equal(got, ref)
+
+
+# ---------------------------------------------------------------------------- edge cases
+@pytest.mark.parametrize("B,T,L", [(1, 2, 1), (1, 8, 3), (17, 8, 5), (33, 6, 2)])
+@pytest.mark.parametrize("precision", ["f32", "bf16x3"])
+def test_forward_edge_shapes_against_oracle(B, T, L, precision):
+    """Smallest legal input (one output frame, one canonical phoneme), batch sizes that are not multiples of the
+    MFMA tile, ragged padding -- reference geometry, against the CPU oracle."""
+    geom = synth.Geometry(**synth.REFERENCE)
+    sd = synth.synth_state_dict(geom, seed=4321)
+    x, x1, _, _ = synth.synth_batch(geom, B=B, T=T, L=L, seed=B * 100 + T, ragged=True)
+    m = _hip().HipModel(geom, sd, precision=precision)
+    got = m.forward(_cuda(x), _cuda(x1), sync_errors=True).cpu().numpy()
+    np.testing.assert_allclose(got, oracle.forward(sd, x, x1), rtol=0, atol=TOL)
+
+
+@pytest.mark.parametrize("B", [100, 256, 300, 512])
+def test_persistent_lstm_batch_sizes_match_step_kernels(B, monkeypatch):
+    """Every team geometry of the persistent BiLSTM (granule form for B <= 256, counter form above) against the
+    per-step split-bf16 kernels, bit for bit; short sequence, full width."""
+    geom = synth.Geometry(**synth.REFERENCE)
+    sd = synth.synth_state_dict(geom, seed=77)
+    x, x1, _, _ = synth.synth_batch(geom, B=B, T=40, L=6, seed=B, ragged=True)
+    monkeypatch.setenv("MDD_LSTM", "x3")
+    ref = _hip().HipModel(geom, sd, precision="bf16x3").forward(_cuda(x), _cuda(x1), sync_errors=True).cpu().numpy()
+    monkeypatch.delenv("MDD_LSTM")
+    got = _hip().HipModel(geom, sd, precision="bf16x3").forward(_cuda(x), _cuda(x1), sync_errors=True).cpu().numpy()
+    np.testing.assert_array_equal(got, ref)
+    monkeypatch.setenv("MDD_LSTM", "counter")
+    got2 = _hip().HipModel(geom, sd, precision="bf16x3").forward(_cuda(x), _cuda(x1), sync_errors=True).cpu().numpy()
+    np.testing.assert_array_equal(got2, ref)
+
+
+def test_decoders_edge_cases_against_oracle():
+    from ctc_attention_mispronunciation_amd.utils.ctcDecoder import GreedyDecoder, BeamDecoder
+    i2c = synth.phone_table_41()
+    Cn, T = 45, 12
+    lp = np.stack([synth.peaky_logp(T, Cn, 5, seed=s) for s in range(5)], axis=1)
+    lens = [0, 1, T, T + 50, 3]                     # empty, single frame, full, longer than the tensor (clamped), short
+    gd = GreedyDecoder(i2c, space_idx=-1, blank_index=0)
+    ids, n = gd.decode_ids(torch.from_numpy(lp).cuda(), lens)
+    ids, n = ids.cpu().numpy(), n.cpu().numpy()
+    assert [ids[b, :n[b]].tolist() for b in range(5)] == oracle.greedy(lp, [min(v, T) for v in lens])
+    assert gd.decode(torch.from_numpy(lp), lens)[0] == ""
+    for width in (1, 10, 16, 40):                   # 40 > fast-path limit: generic kernel
+        bd = BeamDecoder(i2c, beam_width=width, blank_index=0, space_idx=-1, lm_path=os.path.join(GOLD, "lm_synth45.arpa"), lm_alpha=0.25)
+        ids, n, st, sc = bd.decode_ids(torch.from_numpy(lp).cuda(), lens)
+        want, wst, wsc = oracle.beam(lp, lens, bd.lm.dense_table(i2c, Cn), beam_width=width, alpha=0.25, return_scores=True)
+        np.testing.assert_array_equal(st.cpu().numpy(), wst)
+        assert wst[0] == 1                           # no frames -> IndexError in the reference
+        ids, n = ids.cpu().numpy(), n.cpu().numpy()
+        assert [ids[b, :n[b]].tolist() for b in range(5)] == want, width
+    with pytest.raises(IndexError):
+        bd.decode(torch.from_numpy(lp), lens)
+
+
+def test_ctc_edge_cases_against_oracle():
+    rs = np.random.Generator(np.random.PCG64(5))
+    T, B, Cn, Lmax = 9, 4, 7, 4
+    lp = torch.log_softmax(torch.from_numpy(rs.standard_normal((T, B, Cn)).astype(np.float32)), -1).numpy()
+    tg = np.array([[1, 1, 1, 1], [2, 3, 0, 0], [4, 0, 0, 0], [5, 6, 5, 6]])
+    il = np.array([9, 5, 1, 9]); tl = np.array([4, 2, 1, 4])          # repeats need blanks: row 0 is barely feasible (T = 2L+1... 9 >= 7)
+    nll, grad = _hip().ctc_loss(_cuda(lp), _cuda(tg), _cuda(il), _cuda(tl))
+    onll, ograd = oracle.ctc_loss(lp, tg, il, tl)
+    ref = torch.nn.CTCLoss(reduction="none")(torch.from_numpy(lp), torch.from_numpy(tg), torch.from_numpy(il), torch.from_numpy(tl)).numpy()
+    np.testing.assert_allclose(nll.cpu().numpy(), ref, rtol=1e-5)
+    np.testing.assert_allclose(nll.cpu().numpy(), onll, rtol=1e-6)
+    np.testing.assert_allclose(grad.cpu().numpy(), ograd, rtol=0, atol=2e-6)
+    nll_only, g = _hip().ctc_loss(_cuda(lp), _cuda(tg), _cuda(il), _cuda(tl), want_grad=False)
+    assert g is None
+    np.testing.assert_array_equal(nll_only.cpu().numpy(), nll.cpu().numpy())
