@@ -190,7 +190,7 @@ def main():
         x3 = model.precision == "bf16x3"
         def kernel_of(name):
             if name.startswith("lstm"):
-                return "lstm_layer_granule_kernel" if (x3 and B <= 256) else ("lstm_layer_persistent_kernel" if x3 else "lstm_step_packed_kernel")
+                return "lstm_layer_granule_kernel" if (x3 and B <= 512) else ("lstm_layer_persistent_kernel" if x3 else "lstm_step_packed_kernel")
             if name.startswith("gemm"):
                 return "gemm_bf16x3_kernel" if x3 else "gemm_nt_f32_kernel"
             return name

@@ -58,6 +58,7 @@ struct mdd_model {
     int W1() const { return (cfg.feat + 2 - 3) / 2 + 1; }
     int W2() const { return (W1() + 2 - 3) / 2 + 1; }
     int rnn_in() const { return cfg.channels * W2(); }
+    int granule_max_b = 512;    // MDD_GRANULE_MAXB
     bool lstm_granule = true;   // persistent kernel with the data-tagged hand-off (MDD_LSTM=counter selects the counter form)
     bool lstm_persist = true;   // one persistent team-synchronised launch per BiLSTM layer (split-bf16 mode, >= 256 CUs, B <= 512)
     int n_cu = 0;
@@ -226,7 +227,7 @@ static int run_stage(mdd_model *m, int si, const float *x, int B, int T, const i
             a.out_split = x3 ? split_view(m->act_s[n & 1], rows * H2) : kNoSplit;
             a.oscale = m->bn_scale[n + 1]; a.oshift = m->bn_shift[n + 1];
         }
-        if (m->persist(B)) { info->launches = 1; return ((m->lstm_granule && B <= 256) ? launch_lstm_layer_granule : launch_lstm_layer_persistent)(a, reinterpret_cast<unsigned short *>(m->hx.p), m->sync_words, m->err_flag, st); }
+        if (m->persist(B)) { info->launches = 1; return ((m->lstm_granule && B <= m->granule_max_b) ? launch_lstm_layer_granule : launch_lstm_layer_persistent)(a, reinterpret_cast<unsigned short *>(m->hx.p), m->sync_words, m->err_flag, st); }
         return launch_lstm_layer(a, st);
     }
     si -= 2 * nl;
@@ -248,7 +249,7 @@ static int run_stage(mdd_model *m, int si, const float *x, int B, int T, const i
         a.out_split = x3 ? split_view(m->text_s, trows * H2) : kNoSplit;
         a.T = L; a.B = B; a.H = H; a.packed = use_packed(m);
         a.whh_split = m->t_whh_s; a.hsplit = (x3 && m->lstm_x3) ? reinterpret_cast<unsigned short *>(m->hsplit.p) : nullptr;
-        if (m->persist(B)) { info->launches = 1; return ((m->lstm_granule && B <= 256) ? launch_lstm_layer_granule : launch_lstm_layer_persistent)(a, reinterpret_cast<unsigned short *>(m->hx.p), m->sync_words, m->err_flag, st); }
+        if (m->persist(B)) { info->launches = 1; return ((m->lstm_granule && B <= m->granule_max_b) ? launch_lstm_layer_granule : launch_lstm_layer_persistent)(a, reinterpret_cast<unsigned short *>(m->hx.p), m->sync_words, m->err_flag, st); }
         return launch_lstm_layer(a, st);
     }
     case 3:
@@ -309,6 +310,7 @@ extern "C" int mdd_create(const mdd_config *cfg, int device, mdd_model **out) {
     m->lstm_x3 = lx && !strcmp(lx, "x3");
     if (lx && !strcmp(lx, "step")) m->lstm_persist = false;
     if (lx && !strcmp(lx, "counter")) m->lstm_granule = false;
+    if (getenv("MDD_GRANULE_MAXB")) m->granule_max_b = atoi(getenv("MDD_GRANULE_MAXB"));
     const char *g = getenv("MDD_GRAPH");
     m->use_graph = !(g && g[0] == '0');
     if (int rc = init_kernel_attributes()) { delete m; return rc; }
@@ -616,7 +618,7 @@ extern "C" const float *mdd_tap(mdd_model *m, const char *name, int64_t *numel) 
         p = dst.p;
     }
     else if (n == "lstm_dbg" && m->hx.p) {   // diagnostic stamps of the last persistent layer launch (MDD_LSTM_DBG=1)
-        p = (m->lstm_granule && B <= 256) ? m->hx.p + (size_t)2 * 32 * granule_bg(B) * m->cfg.hidden * 2
+        p = (m->lstm_granule && B <= m->granule_max_b) ? m->hx.p + (size_t)2 * 32 * granule_bg(B) * m->cfg.hidden * 2
                             : m->hx.p + (size_t)2 * 16 * 2 * persistent_bg(B) * m->cfg.hidden / 2;
         ne = 256 * 6 * 2;
     }

@@ -13,10 +13,15 @@
 // weights are split once at load time), so this kernel moves the same 4 bytes per element an fp32 GEMM
 // would and spends no VALU on conversion.
 //
-// Tiling: 128x128 block tile, BK = 32, 256 threads = 4 waves (2x2), each wave 64x64 = 2x2 MFMA tiles of
+// Three kernels share the fragment / swizzle helpers below: LDS-DMA 256x256 (large projections: 48 % of the bf16
+// matrix-core peak, 1.54x the register-staged kernel), LDS-DMA 128x128 (small / batched / split-output GEMMs) and the
+// register-staged 128x128 kernel (MDD_GEMM=regs; kept for the ablation study in tools/gemm_ablation.py).
+// Register-staged tiling: 128x128 block tile, BK = 32, 256 threads = 4 waves (2x2), each wave 64x64 = 2x2 MFMA tiles of
 // 32x32 (64 accumulator VGPRs), 24 MFMAs per wave per K-tile, 2 workgroups per CU.  Four bf16 planes (A hi/lo,
 // W hi/lo) are staged global -> registers -> LDS; loads are issued per PAIR of K-tiles (whole 128-byte lines)
 // one pair ahead of the MFMAs (two LDS stages, one barrier per K-tile).
+#include <string.h>
+
 #include "mdd_internal.h"
 
 namespace mdd {
@@ -201,46 +206,121 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(const unsigned shor
         }
 }
 
-// ---- 256x256 tile variant for the large projections: 512 threads = 8 waves (2 x 4), each wave 128x64 = 4x2 MFMA tiles
-// (128 accumulator VGPRs), one workgroup per CU, two waves per SIMD.  A 256x256 tile moves half the bytes per flop of the
-// 128x128 tile through the L2 -> LDS fill path, which is what bounds these GEMMs (see the ablation note above).
-constexpr int YBM = 256, YBN = 256, YPLANE = YBM * XROW;    // 16384 B per plane
-constexpr int YPT = YBM * 4 / 512;                          // 16-byte chunks per thread per plane per K-tile (2)
+// ---- LDS-DMA variant of the 128x128 kernel: tiles go global -> LDS directly (global_load_lds_dwordx4), no staging
+// registers and no ds_write pass.  The LDS image is lane-linear per wave-instruction (64 x 16 B = 16 rows of one plane),
+// so the XOR swizzle is applied to the per-lane SOURCE address; fragment reads use the same swizzle (x3_frag).
+typedef __attribute__((address_space(3))) void lds_void;
 
-__device__ __forceinline__ void y3_load(const unsigned short *__restrict__ Ph, const unsigned short *__restrict__ Pl, int ld,
-                                        int rows_total, int K, int row0, int k0, int tid, u32x4 (&rh)[YPT], u32x4 (&rl)[YPT]) {
+__device__ __forceinline__ void x3_glds_tile(const unsigned short *__restrict__ Ah, const unsigned short *__restrict__ Al,
+                                             const unsigned short *__restrict__ Wh, const unsigned short *__restrict__ Wl, int lda, int ldw,
+                                             int M, int N, int m0, int n0, int k0, unsigned char *stage, int wave, int lane) {
+    // wave w issues 8 instructions: plane p = j>>1, 16-row group g = (j&1)*4 + w
 #pragma unroll
-    for (int i = 0; i < YPT; i++) {
-        const int q = tid + 512 * i, row = min(row0 + (q >> 2), rows_total - 1), k = k0 + (q & 3) * 8;
-        const size_t off = (size_t)row * ld + min(k, K - 8);
-        const u32x4 vh = *reinterpret_cast<const u32x4 *>(Ph + off), vl = *reinterpret_cast<const u32x4 *>(Pl + off);
-        const u32x4 z = {0u, 0u, 0u, 0u};
-        rh[i] = k < K ? vh : z;
-        rl[i] = k < K ? vl : z;
-    }
-}
-__device__ __forceinline__ void y3_store(unsigned char *ph, unsigned char *pl, int tid, const u32x4 (&rh)[YPT], const u32x4 (&rl)[YPT]) {
-#pragma unroll
-    for (int i = 0; i < YPT; i++) {
-        const int q = tid + 512 * i, row = q >> 2, off = row * XROW + (((q & 3) ^ ((row >> 2) & 3)) << 4);
-        *reinterpret_cast<u32x4 *>(ph + off) = rh[i];
-        *reinterpret_cast<u32x4 *>(pl + off) = rl[i];
+    for (int j = 0; j < 8; j++) {
+        const int p = j >> 1, g = (j & 1) * 4 + wave;
+        const int row = g * 16 + (lane >> 2), cp = lane & 3, c = cp ^ ((row >> 2) & 3);
+        const unsigned short *base = p == 0 ? Ah : (p == 1 ? Al : (p == 2 ? Wh : Wl));
+        const int ld = p < 2 ? lda : ldw, rtot = p < 2 ? M : N, r0 = p < 2 ? m0 : n0;
+        const unsigned short *src = base + (size_t)min(r0 + row, rtot - 1) * ld + k0 + c * 8;
+        __builtin_amdgcn_global_load_lds(src, (lds_void *)(stage + p * XPLANE + g * 1024), 16, 0, 0);
     }
 }
 
-__global__ __launch_bounds__(512, 2) void gemm_bf16x3_256_kernel(const unsigned short *__restrict__ Ah, const unsigned short *__restrict__ Al,
-                                                                  const unsigned short *__restrict__ Wh, const unsigned short *__restrict__ Wl,
-                                                                  const float *__restrict__ bias, float *__restrict__ C, int M, int N, int K,
-                                                                  int lda, int ldw, int ldc, int tiles_n) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char ylds[];   // [2 stages][Ah,Al,Wh,Wl][YPLANE] = 128 KB
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+template <int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_bf16x3_glds_kernel(const unsigned short *__restrict__ Ah, const unsigned short *__restrict__ Al,
+                                                                   const unsigned short *__restrict__ Wh, const unsigned short *__restrict__ Wl,
+                                                                   const float *__restrict__ bias, float *__restrict__ C,
+                                                                   unsigned short *__restrict__ Ch, unsigned short *__restrict__ Cl, int M, int N,
+                                                                   int K, int lda, int ldw, int ldc, long sA, long sW, long sC, int tiles_n) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2][4 * XPLANE];   // one array: [stage][Ah|Al|Wh|Wl]
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    int nwg = gridDim.x, bid = blockIdx.x;
+    int q = nwg >> 3, rem = nwg & 7, xcd = bid & 7;
+    int swz = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + (bid >> 3);
+    const int tm = swz / tiles_n, tn = swz % tiles_n;
+    const int m0 = tm * XBM, n0 = tn * XBN;
+    Ah += (size_t)blockIdx.z * sA; Al += (size_t)blockIdx.z * sA;
+    Wh += (size_t)blockIdx.z * sW; Wl += (size_t)blockIdx.z * sW;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+    const int nk = K / XBK;
+    const int li = lane & 31, kb = (lane >> 5) * 16;
+    x3_glds_tile(Ah, Al, Wh, Wl, lda, ldw, M, N, m0, n0, 0, lds[0], wave, lane);
+    __syncthreads();   // hipcc drains the LDS-DMA (vmcnt(0)) ahead of the barrier
+    for (int kt = 0; kt < nk; kt++) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) x3_glds_tile(Ah, Al, Wh, Wl, lda, ldw, M, N, m0, n0, (kt + 1) * XBK, lds[cur ^ 1], wave, lane);
+        const unsigned char *st = lds[cur];
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++) {
+            bf16x8 fah[2], fal[2], fwh[2], fwl[2];
+#pragma unroll
+            for (int i = 0; i < 2; i++) {
+                fah[i] = x3_frag(st, wm * 64 + i * 32 + li, ks * 32 + kb);
+                fal[i] = x3_frag(st + XPLANE, wm * 64 + i * 32 + li, ks * 32 + kb);
+                fwh[i] = x3_frag(st + 2 * XPLANE, wn * 64 + i * 32 + li, ks * 32 + kb);
+                fwl[i] = x3_frag(st + 3 * XPLANE, wn * 64 + i * 32 + li, ks * 32 + kb);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; i++)
+#pragma unroll
+                for (int j = 0; j < 2; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fah[i], fwl[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 2; i++)
+#pragma unroll
+                for (int j = 0; j < 2; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fal[i], fwh[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 2; i++)
+#pragma unroll
+                for (int j = 0; j < 2; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fah[i], fwh[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    const int lh = lane >> 5;
+    if (EPI == 0) C += (size_t)blockIdx.z * sC; else { Ch += (size_t)blockIdx.z * sC; Cl += (size_t)blockIdx.z * sC; }
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const int col = n0 + wn * 64 + j * 32 + li;
+            if (col >= N) continue;
+            const float bv = bias ? bias[col] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (row >= M) continue;
+                const float v = acc[i][j][r] + bv;
+                if (EPI == 0) C[(size_t)row * ldc + col] = v;
+                else {
+                    const unsigned short h = bf16_bits(v);
+                    Ch[(size_t)row * ldc + col] = h;
+                    Cl[(size_t)row * ldc + col] = bf16_bits(v - bf16_to_f32(h));
+                }
+            }
+        }
+}
+
+// ---- LDS-DMA, 256x256 tile, 8 waves (2 x 4), per wave 128x64: half the L2 -> LDS bytes per flop of the 128x128 tile.
+__global__ __launch_bounds__(512, 2) void gemm_bf16x3_glds256_kernel(const unsigned short *__restrict__ Ah, const unsigned short *__restrict__ Al,
+                                                                      const unsigned short *__restrict__ Wh, const unsigned short *__restrict__ Wl,
+                                                                      const float *__restrict__ bias, float *__restrict__ C, int M, int N, int K,
+                                                                      int lda, int ldw, int ldc, int tiles_n) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char glds_smem[];   // [2 stages][Ah|Al|Wh|Wl][256 rows x 64 B] = 128 KB
+    constexpr int PL = 256 * XROW;                                              // 16 KB per plane
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3;
     int nwg = gridDim.x, bid = blockIdx.x;
     int q = nwg >> 3, rem = nwg & 7, xcd = bid & 7;
     int swz = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + (bid >> 3);
     const int tm = swz / tiles_n, tn = swz % tiles_n;
-    const int m0 = tm * YBM, n0 = tn * YBN;
-    auto plane = [&](int stage, int p) { return ylds + ((size_t)stage * 4 + p) * YPLANE; };
+    const int m0 = tm * 256, n0 = tn * 256;
 
     f32x16 acc[4][2];
 #pragma unroll
@@ -249,33 +329,37 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16x3_256_kernel(const unsigned 
         for (int j = 0; j < 2; j++)
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
-
-    u32x4 ah[YPT], al[YPT], wh[YPT], wl[YPT];
-    const int nk = (K + XBK - 1) / XBK;
+    auto fill = [&](int k0, unsigned char *stage) {
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const int id = j * 8 + wave, p = id >> 4, g = id & 15;
+            const int row = g * 16 + (lane >> 2), cp = lane & 3, c = cp ^ ((row >> 2) & 3);
+            const unsigned short *base = p == 0 ? Ah : (p == 1 ? Al : (p == 2 ? Wh : Wl));
+            const int ld = p < 2 ? lda : ldw, rtot = p < 2 ? M : N, r0 = p < 2 ? m0 : n0;
+            const unsigned short *src = base + (size_t)min(r0 + row, rtot - 1) * ld + k0 + c * 8;
+            __builtin_amdgcn_global_load_lds(src, (lds_void *)(stage + p * PL + g * 1024), 16, 0, 0);
+        }
+    };
+    const int nk = K / XBK;
     const int li = lane & 31, kb = (lane >> 5) * 16;
-    y3_load(Ah, Al, lda, M, K, m0, 0, tid, ah, al);
-    y3_load(Wh, Wl, ldw, N, K, n0, 0, tid, wh, wl);
-    y3_store(plane(0, 0), plane(0, 1), tid, ah, al);
-    y3_store(plane(0, 2), plane(0, 3), tid, wh, wl);
+    fill(0, glds_smem);
     __syncthreads();
     for (int kt = 0; kt < nk; kt++) {
         const int cur = kt & 1;
-        if (kt + 1 < nk) {
-            y3_load(Ah, Al, lda, M, K, m0, (kt + 1) * XBK, tid, ah, al);
-            y3_load(Wh, Wl, ldw, N, K, n0, (kt + 1) * XBK, tid, wh, wl);
-        }
+        if (kt + 1 < nk) fill((kt + 1) * XBK, glds_smem + (cur ^ 1) * 4 * PL);
+        const unsigned char *st = glds_smem + cur * 4 * PL;
 #pragma unroll
         for (int ks = 0; ks < 2; ks++) {
             bf16x8 fwh[2], fwl[2];
 #pragma unroll
             for (int j = 0; j < 2; j++) {
-                fwh[j] = x3_frag(plane(cur, 2), wn * 64 + j * 32 + li, ks * 32 + kb);
-                fwl[j] = x3_frag(plane(cur, 3), wn * 64 + j * 32 + li, ks * 32 + kb);
+                fwh[j] = x3_frag(st + 2 * PL, wn * 64 + j * 32 + li, ks * 32 + kb);
+                fwl[j] = x3_frag(st + 3 * PL, wn * 64 + j * 32 + li, ks * 32 + kb);
             }
 #pragma unroll
             for (int i = 0; i < 4; i++) {
-                const bf16x8 fah = x3_frag(plane(cur, 0), wm * 128 + i * 32 + li, ks * 32 + kb);
-                const bf16x8 fal = x3_frag(plane(cur, 1), wm * 128 + i * 32 + li, ks * 32 + kb);
+                const bf16x8 fah = x3_frag(st, wm * 128 + i * 32 + li, ks * 32 + kb);
+                const bf16x8 fal = x3_frag(st + PL, wm * 128 + i * 32 + li, ks * 32 + kb);
 #pragma unroll
                 for (int j = 0; j < 2; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fah, fwl[j], acc[i][j], 0, 0, 0);
 #pragma unroll
@@ -283,10 +367,6 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16x3_256_kernel(const unsigned 
 #pragma unroll
                 for (int j = 0; j < 2; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fah, fwh[j], acc[i][j], 0, 0, 0);
             }
-        }
-        if (kt + 1 < nk) {
-            y3_store(plane(cur ^ 1, 0), plane(cur ^ 1, 1), tid, ah, al);
-            y3_store(plane(cur ^ 1, 2), plane(cur ^ 1, 3), tid, wh, wl);
         }
         __syncthreads();
     }
@@ -307,7 +387,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16x3_256_kernel(const unsigned 
 }
 
 int init_gemm_attributes() {
-    MDD_HIP_CHECK(hipFuncSetAttribute((const void *)gemm_bf16x3_256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 4 * YPLANE));
+    MDD_HIP_CHECK(hipFuncSetAttribute((const void *)gemm_bf16x3_glds256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 4 * 256 * XROW));
     return MDD_OK;
 }
 
@@ -317,10 +397,23 @@ int launch_gemm_bf16x3(const SplitPtr &A, const SplitPtr &W, const float *bias, 
         set_error("gemm_bf16x3: bad shape M=%d N=%d K=%d lda=%d ldw=%d", M, N, K, lda, ldw);
         return MDD_ERR_ARG;
     }
-    if (!Csplit && batch == 1 && M >= 2048 && N >= 512 && getenv("MDD_GEMM256")) {   // opt-in 256x256 tiles (measured slower: 3.28 vs 2.95 ms)
-        const int tm = (M + YBM - 1) / YBM, tn = (N + YBN - 1) / YBN;
-        hipLaunchKernelGGL(gemm_bf16x3_256_kernel, dim3(tm * tn), dim3(512), 2 * 4 * YPLANE, st, A.hi, A.lo, W.hi, W.lo, bias, C, M, N, K,
-                           lda, ldw, ldc, tn);
+    static const int mode = getenv("MDD_GEMM") ? (!strcmp(getenv("MDD_GEMM"), "regs") ? 0 : (!strcmp(getenv("MDD_GEMM"), "glds128") ? 1 : 2)) : 2;
+    if (mode == 2 && !Csplit && batch == 1 && M >= 1024 && N >= 512) {   // large projection: LDS-DMA, 256x256 tiles
+        const int tn = (N + 255) / 256;
+        hipLaunchKernelGGL(gemm_bf16x3_glds256_kernel, dim3(((M + 255) / 256) * tn), dim3(512), 2 * 4 * 256 * XROW, st, A.hi, A.lo, W.hi, W.lo, bias,
+                           C, M, N, K, lda, ldw, ldc, tn);
+        MDD_LAUNCH_CHECK();
+        return MDD_OK;
+    }
+    if (mode >= 1 && K % XBK == 0) {                                     // LDS-DMA, 128x128 tiles (also batched / split output)
+        const int tm = (M + XBM - 1) / XBM, tn = (N + XBN - 1) / XBN;
+        dim3 grid(tm * tn, 1, batch), block(256);
+        if (Csplit)
+            hipLaunchKernelGGL(gemm_bf16x3_glds_kernel<1>, grid, block, 0, st, A.hi, A.lo, W.hi, W.lo, bias, (float *)nullptr, Csplit->hi, Csplit->lo,
+                               M, N, K, lda, ldw, ldc, sA, sW, sC, tn);
+        else
+            hipLaunchKernelGGL(gemm_bf16x3_glds_kernel<0>, grid, block, 0, st, A.hi, A.lo, W.hi, W.lo, bias, C, (unsigned short *)nullptr,
+                               (unsigned short *)nullptr, M, N, K, lda, ldw, ldc, sA, sW, sC, tn);
         MDD_LAUNCH_CHECK();
         return MDD_OK;
     }
@@ -355,6 +448,18 @@ extern "C" int mdd_diag_gemm(int M, int N, int K, int abl, int iters, float *ms_
         if (it == 0) hipEventRecord(e0, nullptr);
 #define LAUNCH_ABL(X) hipLaunchKernelGGL((gemm_bf16x3_kernel<0, X>), grid, block, 0, nullptr, A, A + (size_t)M * K, W, W + (size_t)N * K, (const float *)nullptr, C, \
                                           (unsigned short *)nullptr, (unsigned short *)nullptr, M, N, K, K, K, N, 0l, 0l, 0l, tiles_n)
+        if (abl == 9) {
+            static bool at = false; if (!at) { init_gemm_attributes(); at = true; }
+            const int t256n = (N + 255) / 256;
+            hipLaunchKernelGGL(gemm_bf16x3_glds256_kernel, dim3(((M + 255) / 256) * t256n), dim3(512), 2 * 4 * 256 * XROW, nullptr, A, A + (size_t)M * LD, W, W + (size_t)N * LD,
+                               (const float *)nullptr, C, M, N, K, LD, LD, N, t256n);
+            continue;
+        }
+        if (abl == 8) {
+            hipLaunchKernelGGL((gemm_bf16x3_glds_kernel<0>), grid, block, 0, nullptr, A, A + (size_t)M * LD, W, W + (size_t)N * LD, (const float *)nullptr, C,
+                               (unsigned short *)nullptr, (unsigned short *)nullptr, M, N, K, LD, LD, N, 0l, 0l, 0l, tiles_n);
+            continue;
+        }
         switch (abl) { case 0: LAUNCH_ABL(0); break; case 1: LAUNCH_ABL(1); break; case 2: LAUNCH_ABL(2); break; case 3: LAUNCH_ABL(3); break;
                        case 6: LAUNCH_ABL(6); break; default: LAUNCH_ABL(7); }
 #undef LAUNCH_ABL
