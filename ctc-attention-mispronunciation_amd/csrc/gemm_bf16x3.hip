@@ -308,6 +308,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_glds_kernel(const unsigned
 }
 
 // ---- LDS-DMA, 256x256 tile, 8 waves (2 x 4), per wave 128x64: half the L2 -> LDS bytes per flop of the 128x128 tile.
+template <int SHAPE>
 __global__ __launch_bounds__(512, 2) void gemm_bf16x3_glds256_kernel(const unsigned short *__restrict__ Ah, const unsigned short *__restrict__ Al,
                                                                       const unsigned short *__restrict__ Wh, const unsigned short *__restrict__ Wl,
                                                                       const float *__restrict__ bias, float *__restrict__ C, int M, int N, int K,
@@ -322,13 +323,22 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16x3_glds256_kernel(const unsig
     const int tm = swz / tiles_n, tn = swz % tiles_n;
     const int m0 = tm * 256, n0 = tn * 256;
 
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
     f32x16 acc[4][2];
+    f32x4 acc16[8][4];
+    if (SHAPE == 0) {
 #pragma unroll
-    for (int i = 0; i < 4; i++)
+        for (int i = 0; i < 4; i++)
 #pragma unroll
-        for (int j = 0; j < 2; j++)
+            for (int j = 0; j < 2; j++)
 #pragma unroll
-            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+                for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+    } else {
+#pragma unroll
+        for (int i = 0; i < 8; i++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) acc16[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
     auto fill = [&](int k0, unsigned char *stage) {
 #pragma unroll
         for (int j = 0; j < 8; j++) {
@@ -348,46 +358,85 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16x3_glds256_kernel(const unsig
         const int cur = kt & 1;
         if (kt + 1 < nk) fill((kt + 1) * XBK, glds_smem + (cur ^ 1) * 4 * PL);
         const unsigned char *st = glds_smem + cur * 4 * PL;
+        if (SHAPE == 0) {
 #pragma unroll
-        for (int ks = 0; ks < 2; ks++) {
-            bf16x8 fwh[2], fwl[2];
+            for (int ks = 0; ks < 2; ks++) {
+                bf16x8 fwh[2], fwl[2];
 #pragma unroll
-            for (int j = 0; j < 2; j++) {
-                fwh[j] = x3_frag(st + 2 * PL, wn * 64 + j * 32 + li, ks * 32 + kb);
-                fwl[j] = x3_frag(st + 3 * PL, wn * 64 + j * 32 + li, ks * 32 + kb);
+                for (int j = 0; j < 2; j++) {
+                    fwh[j] = x3_frag(st + 2 * PL, wn * 64 + j * 32 + li, ks * 32 + kb);
+                    fwl[j] = x3_frag(st + 3 * PL, wn * 64 + j * 32 + li, ks * 32 + kb);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const bf16x8 fah = x3_frag(st, wm * 128 + i * 32 + li, ks * 32 + kb);
+                    const bf16x8 fal = x3_frag(st + PL, wm * 128 + i * 32 + li, ks * 32 + kb);
+#pragma unroll
+                    for (int j = 0; j < 2; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fah, fwl[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+                    for (int j = 0; j < 2; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fal, fwh[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+                    for (int j = 0; j < 2; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fah, fwh[j], acc[i][j], 0, 0, 0);
+                }
+            }
+        } else {   // v_mfma_f32_16x16x32_bf16: one k-step per K-tile; lane (row l&15, k-slice l>>4)
+            const int l16 = lane & 15, kq16 = (lane >> 4) * 16;
+            bf16x8 fwh[4], fwl[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                fwh[j] = x3_frag(st + 2 * PL, wn * 64 + j * 16 + l16, kq16);
+                fwl[j] = x3_frag(st + 3 * PL, wn * 64 + j * 16 + l16, kq16);
             }
 #pragma unroll
-            for (int i = 0; i < 4; i++) {
-                const bf16x8 fah = x3_frag(st, wm * 128 + i * 32 + li, ks * 32 + kb);
-                const bf16x8 fal = x3_frag(st + PL, wm * 128 + i * 32 + li, ks * 32 + kb);
+            for (int i = 0; i < 8; i++) {
+                const bf16x8 fah = x3_frag(st, wm * 128 + i * 16 + l16, kq16);
+                const bf16x8 fal = x3_frag(st + PL, wm * 128 + i * 16 + l16, kq16);
 #pragma unroll
-                for (int j = 0; j < 2; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fah, fwl[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < 4; j++) acc16[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fah, fwl[j], acc16[i][j], 0, 0, 0);
 #pragma unroll
-                for (int j = 0; j < 2; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fal, fwh[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < 4; j++) acc16[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fal, fwh[j], acc16[i][j], 0, 0, 0);
 #pragma unroll
-                for (int j = 0; j < 2; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fah, fwh[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < 4; j++) acc16[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fah, fwh[j], acc16[i][j], 0, 0, 0);
             }
         }
         __syncthreads();
     }
-    const int lh = lane >> 5;
+    if (SHAPE == 0) {
+        const int lh = lane >> 5;
 #pragma unroll
-    for (int i = 0; i < 4; i++)
+        for (int i = 0; i < 4; i++)
 #pragma unroll
-        for (int j = 0; j < 2; j++) {
-            const int col = n0 + wn * 64 + j * 32 + li;
-            if (col >= N) continue;
-            const float bv = bias ? bias[col] : 0.f;
+            for (int j = 0; j < 2; j++) {
+                const int col = n0 + wn * 64 + j * 32 + li;
+                if (col >= N) continue;
+                const float bv = bias ? bias[col] : 0.f;
 #pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const int row = m0 + wm * 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (row < M) C[(size_t)row * ldc + col] = acc[i][j][r] + bv;
+                for (int r = 0; r < 16; r++) {
+                    const int row = m0 + wm * 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    if (row < M) C[(size_t)row * ldc + col] = acc[i][j][r] + bv;
+                }
             }
-        }
+    } else {   // 16x16 C/D: col = lane&15, row = 4*(lane>>4) + r
+        const int l16 = lane & 15, q4 = (lane >> 4) * 4;
+#pragma unroll
+        for (int i = 0; i < 8; i++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int col = n0 + wn * 64 + j * 16 + l16;
+                if (col >= N) continue;
+                const float bv = bias ? bias[col] : 0.f;
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int row = m0 + wm * 128 + i * 16 + q4 + r;
+                    if (row < M) C[(size_t)row * ldc + col] = acc16[i][j][r] + bv;
+                }
+            }
+    }
 }
 
 int init_gemm_attributes() {
-    MDD_HIP_CHECK(hipFuncSetAttribute((const void *)gemm_bf16x3_glds256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 4 * 256 * XROW));
+    MDD_HIP_CHECK(hipFuncSetAttribute((const void *)gemm_bf16x3_glds256_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 4 * 256 * XROW));
+    MDD_HIP_CHECK(hipFuncSetAttribute((const void *)gemm_bf16x3_glds256_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 4 * 256 * XROW));
     return MDD_OK;
 }
 
@@ -400,7 +449,10 @@ int launch_gemm_bf16x3(const SplitPtr &A, const SplitPtr &W, const float *bias, 
     static const int mode = getenv("MDD_GEMM") ? (!strcmp(getenv("MDD_GEMM"), "regs") ? 0 : (!strcmp(getenv("MDD_GEMM"), "glds128") ? 1 : 2)) : 2;
     if (mode == 2 && !Csplit && batch == 1 && M >= 1024 && N >= 512) {   // large projection: LDS-DMA, 256x256 tiles
         const int tn = (N + 255) / 256;
-        hipLaunchKernelGGL(gemm_bf16x3_glds256_kernel, dim3(((M + 255) / 256) * tn), dim3(512), 2 * 4 * 256 * XROW, st, A.hi, A.lo, W.hi, W.lo, bias,
+        static const int shape = getenv("MDD_MFMA32") ? 0 : 1;   // 16x16x32 holds a higher clock on real data: 2.00 vs 2.32 ms in the model
+        if (shape) hipLaunchKernelGGL(gemm_bf16x3_glds256_kernel<1>, dim3(((M + 255) / 256) * tn), dim3(512), 2 * 4 * 256 * XROW, st, A.hi, A.lo, W.hi, W.lo, bias,
+                           C, M, N, K, lda, ldw, ldc, tn);
+        else hipLaunchKernelGGL(gemm_bf16x3_glds256_kernel<0>, dim3(((M + 255) / 256) * tn), dim3(512), 2 * 4 * 256 * XROW, st, A.hi, A.lo, W.hi, W.lo, bias,
                            C, M, N, K, lda, ldw, ldc, tn);
         MDD_LAUNCH_CHECK();
         return MDD_OK;
@@ -451,7 +503,14 @@ extern "C" int mdd_diag_gemm(int M, int N, int K, int abl, int iters, float *ms_
         if (abl == 9) {
             static bool at = false; if (!at) { init_gemm_attributes(); at = true; }
             const int t256n = (N + 255) / 256;
-            hipLaunchKernelGGL(gemm_bf16x3_glds256_kernel, dim3(((M + 255) / 256) * t256n), dim3(512), 2 * 4 * 256 * XROW, nullptr, A, A + (size_t)M * LD, W, W + (size_t)N * LD,
+            hipLaunchKernelGGL(gemm_bf16x3_glds256_kernel<0>, dim3(((M + 255) / 256) * t256n), dim3(512), 2 * 4 * 256 * XROW, nullptr, A, A + (size_t)M * LD, W, W + (size_t)N * LD,
+                               (const float *)nullptr, C, M, N, K, LD, LD, N, t256n);
+            continue;
+        }
+        if (abl == 10) {
+            static bool at = false; if (!at) { init_gemm_attributes(); at = true; }
+            const int t256n = (N + 255) / 256;
+            hipLaunchKernelGGL(gemm_bf16x3_glds256_kernel<1>, dim3(((M + 255) / 256) * t256n), dim3(512), 2 * 4 * 256 * XROW, nullptr, A, A + (size_t)M * LD, W, W + (size_t)N * LD,
                                (const float *)nullptr, C, M, N, K, LD, LD, N, t256n);
             continue;
         }
