@@ -232,6 +232,10 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_glds_kernel(const unsigned
                                                                    const float *__restrict__ bias, float *__restrict__ C,
                                                                    unsigned short *__restrict__ Ch, unsigned short *__restrict__ Cl, int M, int N,
                                                                    int K, int lda, int ldw, int ldc, long sA, long sW, long sC, int tiles_n) {
+    // v_mfma_f32_16x16x32_bf16, per wave 64x64 = 4x4 tiles.  Same shape and product order as the 256x256 kernel, so an
+    // output element is accumulated identically whichever kernel the problem size selects (results do not depend on
+    // how many utterances share the batch, bit for bit).
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
     __shared__ __attribute__((aligned(16))) unsigned char lds[2][4 * XPLANE];   // one array: [stage][Ah|Al|Wh|Wl]
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
@@ -243,58 +247,50 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_glds_kernel(const unsigned
     Ah += (size_t)blockIdx.z * sA; Al += (size_t)blockIdx.z * sA;
     Wh += (size_t)blockIdx.z * sW; Wl += (size_t)blockIdx.z * sW;
 
-    f32x16 acc[2][2];
+    f32x4 acc[4][4];
 #pragma unroll
-    for (int i = 0; i < 2; i++)
+    for (int i = 0; i < 4; i++)
 #pragma unroll
-        for (int j = 0; j < 2; j++)
-#pragma unroll
-            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+        for (int j = 0; j < 4; j++) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int nk = K / XBK;
-    const int li = lane & 31, kb = (lane >> 5) * 16;
+    const int l16 = lane & 15, kq16 = (lane >> 4) * 16;
     x3_glds_tile(Ah, Al, Wh, Wl, lda, ldw, M, N, m0, n0, 0, lds[0], wave, lane);
     __syncthreads();   // hipcc drains the LDS-DMA (vmcnt(0)) ahead of the barrier
     for (int kt = 0; kt < nk; kt++) {
         const int cur = kt & 1;
         if (kt + 1 < nk) x3_glds_tile(Ah, Al, Wh, Wl, lda, ldw, M, N, m0, n0, (kt + 1) * XBK, lds[cur ^ 1], wave, lane);
         const unsigned char *st = lds[cur];
+        bf16x8 fwh[4], fwl[4];
 #pragma unroll
-        for (int ks = 0; ks < 2; ks++) {
-            bf16x8 fah[2], fal[2], fwh[2], fwl[2];
+        for (int j = 0; j < 4; j++) {
+            fwh[j] = x3_frag(st + 2 * XPLANE, wn * 64 + j * 16 + l16, kq16);
+            fwl[j] = x3_frag(st + 3 * XPLANE, wn * 64 + j * 16 + l16, kq16);
+        }
 #pragma unroll
-            for (int i = 0; i < 2; i++) {
-                fah[i] = x3_frag(st, wm * 64 + i * 32 + li, ks * 32 + kb);
-                fal[i] = x3_frag(st + XPLANE, wm * 64 + i * 32 + li, ks * 32 + kb);
-                fwh[i] = x3_frag(st + 2 * XPLANE, wn * 64 + i * 32 + li, ks * 32 + kb);
-                fwl[i] = x3_frag(st + 3 * XPLANE, wn * 64 + i * 32 + li, ks * 32 + kb);
-            }
+        for (int i = 0; i < 4; i++) {
+            const bf16x8 fah = x3_frag(st, wm * 64 + i * 16 + l16, kq16);
+            const bf16x8 fal = x3_frag(st + XPLANE, wm * 64 + i * 16 + l16, kq16);
 #pragma unroll
-            for (int i = 0; i < 2; i++)
+            for (int j = 0; j < 4; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fah, fwl[j], acc[i][j], 0, 0, 0);
 #pragma unroll
-                for (int j = 0; j < 2; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fah[i], fwl[j], acc[i][j], 0, 0, 0);
+            for (int j = 0; j < 4; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fal, fwh[j], acc[i][j], 0, 0, 0);
 #pragma unroll
-            for (int i = 0; i < 2; i++)
-#pragma unroll
-                for (int j = 0; j < 2; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fal[i], fwh[j], acc[i][j], 0, 0, 0);
-#pragma unroll
-            for (int i = 0; i < 2; i++)
-#pragma unroll
-                for (int j = 0; j < 2; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fah[i], fwh[j], acc[i][j], 0, 0, 0);
+            for (int j = 0; j < 4; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fah, fwh[j], acc[i][j], 0, 0, 0);
         }
         __syncthreads();
     }
-    const int lh = lane >> 5;
+    const int q4 = (lane >> 4) * 4;   // 16x16 C/D: col = lane&15, row = 4*(lane>>4) + r
     if (EPI == 0) C += (size_t)blockIdx.z * sC; else { Ch += (size_t)blockIdx.z * sC; Cl += (size_t)blockIdx.z * sC; }
 #pragma unroll
-    for (int i = 0; i < 2; i++)
+    for (int i = 0; i < 4; i++)
 #pragma unroll
-        for (int j = 0; j < 2; j++) {
-            const int col = n0 + wn * 64 + j * 32 + li;
+        for (int j = 0; j < 4; j++) {
+            const int col = n0 + wn * 64 + j * 16 + l16;
             if (col >= N) continue;
             const float bv = bias ? bias[col] : 0.f;
 #pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            for (int r = 0; r < 4; r++) {
+                const int row = m0 + wm * 64 + i * 16 + q4 + r;
                 if (row >= M) continue;
                 const float v = acc[i][j][r] + bv;
                 if (EPI == 0) C[(size_t)row * ldc + col] = v;
