@@ -391,36 +391,60 @@ __global__ __launch_bounds__(64) void beam_kernel(const double *__restrict__ lpw
 //   round-robin the true winners sit in different lanes and theta0 is tight) -> ballot compaction of the ~10-20
 //   candidates >= theta0 -> rank counting among those (rank < keep IS the output position).
 constexpr int FB = 16;   // max beams on the fast path
+typedef double f64x2 __attribute__((ext_vector_type(2)));
 
-template <int NS>
-__global__ __launch_bounds__(64) void beam_fast_kernel(const double *__restrict__ lpw, const unsigned char *__restrict__ flags,
+// Workgroup shape: W = blockDim.x / 64 independent waves, one utterance each, sharing only the LM table.  A beam wave
+// holds ~210 VGPRs, so a CU that hosts one cannot take a workgroup of the forward's GEMM (2 x 256 VGPRs per SIMD) or
+// persistent BiLSTM (414): dealt one wave per CU the search would fence the whole chip off from the next batch's
+// forward for its entire duration.  Packed W to a CU (two per SIMD, latency-bound so they interleave for free) it
+// occupies B / W CUs and the forward keeps the rest.  Waves never meet at a workgroup barrier after the LM load
+// (utterance lengths differ); inside a wave, LDS operations complete in order, so a wave-scope fence is the only
+// synchronisation between the phases.
+#define BEAM_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); \
+                              __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
+
+// LDS bytes of one wave's private state (NS*64 slots, beam prefixes of up to Tcap ids)
+__host__ __device__ inline size_t beam_fast_wave_bytes(int NS, int beam, int Tcap) {
+    return sizeof(double) * ((size_t)2 * NS * 64 + 64 + 6 * FB + 4 * FB) + sizeof(unsigned long long) * 4 * FB +
+           sizeof(int) * ((size_t)2 * NS * 64 + 4 * FB + 3 * FB) + (size_t)(2 * beam + 1) * Tcap;
+}
+
+template <int NS, bool DBG>
+__global__ __launch_bounds__(NS == 8 ? 512 : 256) void beam_fast_kernel(const double *__restrict__ lpw, const unsigned char *__restrict__ flags,
                                                        int T, int B, int C, const int32_t *__restrict__ len, int beam, int blank,
                                                        const double *__restrict__ lm, double alpha, int32_t *__restrict__ ids,
                                                        int32_t *__restrict__ nids, int32_t *__restrict__ status,
-                                                       double *__restrict__ score, int Tcap) {
+                                                       double *__restrict__ score, int Tcap, long long *__restrict__ dbg) {
     extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
     const int C1 = C + 1;
-    double *tot = reinterpret_cast<double *>(sm);                     // [NS*64]
-    double *lmt = tot + NS * 64;                                       // [C1*C1]
-    double *cl_v = lmt + C1 * C1;                                      // [NS*64] compacted candidates: value,
-    int *cl_o = reinterpret_cast<int *>(cl_v + NS * 64);               //   insertion order,
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    double *lmt = reinterpret_cast<double *>(sm);                      // [C1*C1], shared by the waves
+    unsigned char *mine = sm + sizeof(double) * (size_t)C1 * C1 + (size_t)wave * ((beam_fast_wave_bytes(NS, beam, Tcap) + 15) & ~(size_t)15);
+    double *tot = reinterpret_cast<double *>(mine);                    // [NS*64]
+    double *cl_v = tot + NS * 64;                                      // [NS*64] compacted candidates: value,
+    double *lp = cl_v + NS * 64;                                       // [64]
+    double (*m_T)[FB] = reinterpret_cast<double (*)[FB]>(lp + 64);     // [2][FB] beam state, double-buffered
+    double (*m_NB)[FB] = m_T + 2, (*m_B)[FB] = m_NB + 2;
+    double *cNB = reinterpret_cast<double *>(m_B + 2), *cB = cNB + FB, *cT = cB + FB, *sel_v = cT + FB;
+    unsigned long long (*m_hash)[FB] = reinterpret_cast<unsigned long long (*)[FB]>(sel_v + FB), (*m_phash)[FB] = m_hash + 2;
+    int *cl_o = reinterpret_cast<int *>(m_phash + 2);                  //   insertion order,
     int *cl_x = cl_o + NS * 64;                                        //   slot index
-    unsigned char *fl = reinterpret_cast<unsigned char *>(cl_x + NS * 64);
+    int (*m_len)[FB] = reinterpret_cast<int (*)[FB]>(cl_x + NS * 64), (*m_last)[FB] = m_len + 2;
+    int *parent = reinterpret_cast<int *>(m_last + 2), *mslot = parent + FB, *sel_x = mslot + FB;
+    unsigned char *fl = reinterpret_cast<unsigned char *>(sel_x + FB);
     unsigned char *pref = fl + Tcap;
-    __shared__ double lp[64];
-    __shared__ double m_T[2][FB], m_NB[2][FB], m_B[2][FB];
-    __shared__ unsigned long long m_hash[2][FB], m_phash[2][FB];
-    __shared__ int m_len[2][FB], m_last[2][FB];
-    __shared__ double cNB[FB], cB[FB], cT[FB], sel_v[FB];
-    __shared__ int parent[FB], mslot[FB], sel_x[FB];
 
-    const int b = blockIdx.x, lane = threadIdx.x;
+    for (int i = threadIdx.x; i < C1 * C1; i += blockDim.x) lmt[i] = lm[i];
+    __syncthreads();                                                   // the only workgroup barrier
+    const int b = blockIdx.x * (blockDim.x >> 6) + wave;
+    if (b >= B) return;
     int cur = 0, nb = 1, err = 0;
+    long long ph[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tstamp = 0;   // MDD_BEAM_DBG: cycles per phase
+#define FSTAMP(i) do { if (DBG) { long long now_ = __builtin_readcyclecounter(); ph[i] += now_ - tstamp; tstamp = now_; } } while (0)
     if (lane == 0) {
         m_T[0][0] = 0.0; m_B[0][0] = 0.0; m_NB[0][0] = LOG_ZERO; m_len[0][0] = 0; m_last[0][0] = -1;
         m_hash[0][0] = 0x243F6A8885A308D3ull; m_phash[0][0] = 0;
     }
-    for (int i = lane; i < C1 * C1; i += 64) lmt[i] = lm[i];
     int tl = len[b];
     tl = tl < 0 ? 0 : (tl > T ? T : tl);
     for (int i = lane; i < tl; i += 64) fl[i] = flags[(size_t)i * B + b];
@@ -433,21 +457,23 @@ __global__ __launch_bounds__(64) void beam_fast_kernel(const double *__restrict_
         so[i] = sr[i] * C + (sk[i] == blank ? 0 : (sk[i] < blank ? sk[i] + 1 : sk[i]));   // insertion order of the slot
     }
     const float invC = 1.0f / (float)C;
-    __syncthreads();
+    BEAM_WAVE_SYNC();
 
     int t = 0;
     while (t < tl && !(fl[t] & 1)) t++;
     double pre = (t < tl && lane < C) ? lpw[((size_t)t * B + b) * C + lane] : 0.0;
+    if (DBG) tstamp = __builtin_readcyclecounter();
     while (t < tl) {
         const bool rep_ok = (fl[t] & 2) != 0;
         if (lane < C) lp[lane] = pre;
         int tn = t + 1;
         while (tn < tl && !(fl[tn] & 1)) tn++;
         pre = (tn < tl && lane < C) ? lpw[((size_t)tn * B + b) * C + lane] : 0.0;
-        __syncthreads();
+        BEAM_WAVE_SYNC();
         unsigned char *pcur = pref + (size_t)cur * beam * Tcap, *pnext = pref + (size_t)(cur ^ 1) * beam * Tcap;
         const int nslot = nb * C;
 
+        FSTAMP(0);
         // ---- candidate scores: gather every operand first (independent LDS reads), then store
         int first_err_ord = 0x7fffffff, first_err = 0;
         double val[NS];
@@ -470,6 +496,7 @@ __global__ __launch_bounds__(64) void beam_fast_kernel(const double *__restrict_
 #pragma unroll
         for (int i = 0; i < NS; i++)
             if (sk[i] != blank || lane + 64 * i >= nslot) tot[lane + 64 * i] = val[i];   // copy slots are written below
+        FSTAMP(1);
         // ---- copy path of beam `lane` (:101-113) and its parent candidate
         if (lane < nb) {
             const int ylen = m_len[cur][lane], ylast = m_last[cur][lane];
@@ -491,6 +518,7 @@ __global__ __launch_bounds__(64) void beam_fast_kernel(const double *__restrict_
             parent[lane] = par;
             mslot[lane] = -1;
         }
+        FSTAMP(2);
         // verify the content of every hash match with the whole wave (never merge on a hash collision)
         for (int a = 0; a < nb; a++) {
             const int q = parent[a];
@@ -507,6 +535,7 @@ __global__ __launch_bounds__(64) void beam_fast_kernel(const double *__restrict_
             }
             if (__any(neq) && lane == 0) parent[a] = -1;
         }
+        FSTAMP(3);
         {   // first error in the reference's execution order wins
             int eo = first_err_ord;
             for (int o = 32; o > 0; o >>= 1) eo = min(eo, __shfl_xor(eo, o));
@@ -516,7 +545,8 @@ __global__ __launch_bounds__(64) void beam_fast_kernel(const double *__restrict_
                 break;
             }
         }
-        __syncthreads();
+        BEAM_WAVE_SYNC();
+        FSTAMP(4);
         // ---- merges (see beam_kernel)
         int nmerge = 0;
         if (lane < nb && parent[lane] >= 0) {
@@ -537,7 +567,8 @@ __global__ __launch_bounds__(64) void beam_fast_kernel(const double *__restrict_
             nmerge = 1;
         }
         nmerge = __popcll(__ballot(nmerge != 0));
-        __syncthreads();
+        BEAM_WAVE_SYNC();
+        FSTAMP(5);
         // ---- top-`keep` selection
         const int ncand = nslot - nmerge;
         const int keep = ncand < beam ? ncand : beam;
@@ -547,19 +578,23 @@ __global__ __launch_bounds__(64) void beam_fast_kernel(const double *__restrict_
         double lmax = tv[0];
 #pragma unroll
         for (int i = 1; i < NS; i++) lmax = fmax(lmax, tv[i]);
+        // rank of the lane maximum = lane maxima strictly above it, counted against LDS broadcasts (two per read);
+        // theta0 = the smallest lane maximum of rank < keep: at least `keep` slots are >= theta0
+        cl_v[lane] = lmax;
+        BEAM_WAVE_SYNC();
         int rk = 0;
-        {
-            const int lo = __double2loint(lmax), hi = __double2hiint(lmax);
-#pragma unroll 16
-            for (int j = 0; j < 64; j++) {
-                const double sj = __hiloint2double(__builtin_amdgcn_readlane(hi, j), __builtin_amdgcn_readlane(lo, j));
-                rk += (sj > lmax || (sj == lmax && j < lane)) ? 1 : 0;
-            }
+#pragma unroll 8
+        for (int j = 0; j < 64; j += 2) {
+            const f64x2 sj = *reinterpret_cast<const f64x2 *>(cl_v + j);
+            rk += (sj.x > lmax ? 1 : 0) + (sj.y > lmax ? 1 : 0);
         }
-        const unsigned long long mk = __ballot(rk == keep - 1);
+        unsigned long long mk = 0;
+        for (int r = keep - 1; r >= 0 && mk == 0; r--) mk = __ballot(rk == r);
         const int srcl = __ffsll((long long)mk) - 1;
         const double theta0 = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(lmax), srcl),
                                                __builtin_amdgcn_readlane(__double2loint(lmax), srcl));
+        BEAM_WAVE_SYNC();                                                // cl_v is rewritten by the compaction below
+        FSTAMP(6);
         int nl = 0;
         const unsigned long long lt = (1ull << lane) - 1ull;
 #pragma unroll
@@ -572,7 +607,23 @@ __global__ __launch_bounds__(64) void beam_fast_kernel(const double *__restrict_
             }
             nl += __popcll(msk);
         }
-        __syncthreads();
+        BEAM_WAVE_SYNC();
+        FSTAMP(7);
+        if (nl <= 64) {   // the usual case: one candidate per lane, ranked against v_readlane broadcasts
+            const bool has = lane < nl;
+            const double v_ld = cl_v[lane];                               // unconditional: three loads in flight, not three branches
+            const int o_ld = cl_o[lane], xs = cl_x[lane];
+            const double v = has ? v_ld : -INFINITY;
+            const int o = has ? o_ld : 0x7fffffff;
+            const int vlo = __double2loint(v), vhi = __double2hiint(v);
+            int rank = 0;
+            for (int f = 0; f < nl; f++) {
+                const double vf = __hiloint2double(__builtin_amdgcn_readlane(vhi, f), __builtin_amdgcn_readlane(vlo, f));
+                const int of = __builtin_amdgcn_readlane(o, f);
+                rank += (vf > v || (vf == v && of < o)) ? 1 : 0;
+            }
+            if (has && rank < keep) { sel_v[rank] = v; sel_x[rank] = xs; }
+        } else
         for (int e = lane; e < nl; e += 64) {
             const double v = cl_v[e];
             const int o = cl_o[e];
@@ -585,9 +636,12 @@ __global__ __launch_bounds__(64) void beam_fast_kernel(const double *__restrict_
             }
             if (rank < keep) { sel_v[rank] = v; sel_x[rank] = cl_x[e]; }
         }
-        __syncthreads();
+        BEAM_WAVE_SYNC();
+        FSTAMP(8);
+        if (DBG) ph[11] += nl;
         // ---- materialise the new beams
         const int nxt = cur ^ 1;
+        int app_k = -1, app_at = 0;                                       // id appended to new beam `lane`, and where
         if (lane < keep) {
             const int idx = sel_x[lane];
             const int r = (int)(((float)idx + 0.5f) * invC), k = idx - r * C;
@@ -603,26 +657,37 @@ __global__ __launch_bounds__(64) void beam_fast_kernel(const double *__restrict_
                     if (a < nb && mslot[a] == idx) { nbv = cNB[a]; bv = cB[a]; }
                 const unsigned long long h = m_hash[cur][r];
                 m_T[nxt][lane] = v; m_NB[nxt][lane] = nbv; m_B[nxt][lane] = bv;
-                m_len[nxt][lane] = m_len[cur][r] + 1; m_last[nxt][lane] = k;
+                app_at = m_len[cur][r]; app_k = k;
+                m_len[nxt][lane] = app_at + 1; m_last[nxt][lane] = k;
                 m_phash[nxt][lane] = h; m_hash[nxt][lane] = h * 0x9E3779B97F4A7C15ull + (unsigned long long)(k + 1);
             }
         }
-        for (int i = 0; i < keep; i++) {
-            const int idx = sel_x[i];
-            const int r = (int)(((float)idx + 0.5f) * invC), k = idx - r * C;
-            const int ln = m_len[cur][r];
-            const unsigned int *src = reinterpret_cast<const unsigned int *>(pcur + (size_t)r * Tcap);
-            unsigned int *dst = reinterpret_cast<unsigned int *>(pnext + (size_t)i * Tcap);
-            for (int j = lane; j * 4 < ln; j += 64) dst[j] = src[j];
-            __builtin_amdgcn_wave_barrier();
-            if (k != blank && lane == 0) reinterpret_cast<unsigned char *>(dst)[ln] = (unsigned char)k;
+        FSTAMP(9);
+        {   // prefixes: every new beam copies its parent's whole row (bytes past a prefix's length are never read),
+            // one word per lane and row, all rows in flight together; the appended id goes in afterwards
+            int rr[FB];
+#pragma unroll
+            for (int i = 0; i < FB; i++) rr[i] = (int)(((float)sel_x[i < keep ? i : keep - 1] + 0.5f) * invC);
+            const int nw = Tcap >> 2;
+            const unsigned int *srcw = reinterpret_cast<const unsigned int *>(pcur);
+            unsigned int *dstw = reinterpret_cast<unsigned int *>(pnext);
+            for (int j = lane; j < nw; j += 64) {
+                unsigned int w[FB];
+#pragma unroll
+                for (int i = 0; i < FB; i++) w[i] = srcw[rr[i] * nw + j];
+#pragma unroll
+                for (int i = 0; i < FB; i++) if (i < keep) dstw[i * nw + j] = w[i];
+            }
+            BEAM_WAVE_SYNC();
+            if (lane < keep && app_k >= 0) pnext[(size_t)lane * Tcap + app_at] = (unsigned char)app_k;
         }
-        __syncthreads();
+        BEAM_WAVE_SYNC();
         cur = nxt;
         nb = keep;
         t = tn;
+        FSTAMP(10);
     }
-    __syncthreads();
+    BEAM_WAVE_SYNC();
     if (lane == 0) {   // final: EOS LM term, length normalisation, first maximum (:130-148)
         int best = -1;
         double bestv = 0.0;
@@ -644,7 +709,9 @@ __global__ __launch_bounds__(64) void beam_fast_kernel(const double *__restrict_
         }
         nids[b] = n;
         if (score) score[b] = err ? __builtin_nan("") : bestv;
+        if (DBG) for (int i = 0; i < 12; i++) dbg[b * 12 + i] = ph[i];
     }
+#undef FSTAMP
 }
 
 }  // namespace mdd
@@ -694,16 +761,33 @@ extern "C" int mdd_beam(const float *logp_dev, int32_t T, int32_t B, int32_t C, 
     const int nslots = beam * C;
     if (beam <= FB && C <= 64 && nslots <= 1024 && !getenv("MDD_BEAM_GENERIC")) {
         const int NS = nslots <= 512 ? 8 : 16;
-        const size_t fs = (size_t)NS * 64 * (8 + 8 + 4 + 4) + sizeof(double) * (size_t)(C + 1) * (C + 1) + (size_t)(2 * beam + 1) * Tcap + 16;
+        const size_t lmb = sizeof(double) * (size_t)(C + 1) * (C + 1);
+        const size_t pw = (beam_fast_wave_bytes(NS, beam, Tcap) + 15) & ~(size_t)15;
+        const size_t lds_max = 160 * 1024;
         static bool fattr = false;
         if (!fattr) {
-            MDD_HIP_CHECK(hipFuncSetAttribute((const void *)beam_fast_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024));
-            MDD_HIP_CHECK(hipFuncSetAttribute((const void *)beam_fast_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024));
+            MDD_HIP_CHECK(hipFuncSetAttribute((const void *)beam_fast_kernel<8, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
+            MDD_HIP_CHECK(hipFuncSetAttribute((const void *)beam_fast_kernel<16, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
+            MDD_HIP_CHECK(hipFuncSetAttribute((const void *)beam_fast_kernel<8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
+            MDD_HIP_CHECK(hipFuncSetAttribute((const void *)beam_fast_kernel<16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
             fattr = true;
         }
-        if (fs > 120 * 1024) { (void)hipFreeAsync(lpw, st); set_error("mdd_beam: T too long for LDS (%zu B)", fs); return MDD_ERR_ARG; }
-        if (NS == 8) hipLaunchKernelGGL(beam_fast_kernel<8>, dim3(B), dim3(64), fs, st, lpw, flags, T, B, C, len_dev, beam, blank, lm_dev, lm_alpha, ids_dev, nids_dev, status_dev, score_dev, Tcap);
-        else hipLaunchKernelGGL(beam_fast_kernel<16>, dim3(B), dim3(64), fs, st, lpw, flags, T, B, C, len_dev, beam, blank, lm_dev, lm_alpha, ids_dev, nids_dev, status_dev, score_dev, Tcap);
+        if (lmb + pw > lds_max) { (void)hipFreeAsync(lpw, st); set_error("mdd_beam: T too long for LDS (%zu B)", lmb + pw); return MDD_ERR_ARG; }
+        // waves per workgroup: as many as the LDS holds (<= 8); a small batch spreads out instead (one wave per CU is the
+        // lowest latency when nothing else wants the CUs)
+        int W = (int)((lds_max - lmb) / pw);
+        W = W > 8 ? 8 : W;
+        if (NS == 16 && W > 4) W = 4;                                   // the 1024-slot variant needs > 256 VGPRs
+        if (B <= 64) W = 1;
+        if (const char *we = getenv("MDD_BEAM_W")) { const int w = atoi(we); if (w >= 1 && w <= W) W = w; }
+        const size_t fs = lmb + (size_t)W * pw;
+        const dim3 grid_f((B + W - 1) / W), block_f(64 * W);
+        long long *fdbg = getenv("MDD_BEAM_DBG") ? reinterpret_cast<long long *>(score_dev) + B : nullptr;   // tools/beam_stamps.py
+#define MDD_BEAM_FAST(NS_, DBG_) hipLaunchKernelGGL((beam_fast_kernel<NS_, DBG_>), grid_f, block_f, fs, st, lpw, flags, T, B, C, len_dev, beam, blank, \
+                                                  lm_dev, lm_alpha, ids_dev, nids_dev, status_dev, score_dev, Tcap, fdbg)
+        if (NS == 8) { if (fdbg) MDD_BEAM_FAST(8, true); else MDD_BEAM_FAST(8, false); }
+        else { if (fdbg) MDD_BEAM_FAST(16, true); else MDD_BEAM_FAST(16, false); }
+#undef MDD_BEAM_FAST
     } else
     hipLaunchKernelGGL(beam_kernel, dim3(B), dim3(64), smem, st, lpw, flags, T, B, C, len_dev, beam, blank, lm_dev, lm_alpha,
                        ids_dev, nids_dev, status_dev, score_dev, Tcap, lm_in_lds, getenv("MDD_BEAM_SKIP") ? atoi(getenv("MDD_BEAM_SKIP")) : 0,

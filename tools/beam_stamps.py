@@ -1,4 +1,4 @@
-"""Diagnostic: per-phase cycle shares of beam_kernel (MDD_BEAM_DBG build path; stamps go to a side buffer)."""
+"""Diagnostic: per-phase cycle shares of beam_fast_kernel (MDD_BEAM_DBG; stamps go to a side buffer behind the scores)."""
 import os, sys, ctypes as C
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -6,20 +6,20 @@ os.environ['MDD_BEAM_DBG'] = '1'
 import torch, numpy as np
 from ctc_attention_mispronunciation_amd import synth, _lib
 from ctc_attention_mispronunciation_amd.utils.NgramLM import LanguageModel
-T, B, Cn = 250, 64, 45
+T, B, Cn = 250, int(os.environ.get('B', '64')), 45
 z = np.random.Generator(np.random.PCG64(1)).standard_normal((T, B, Cn)).astype(np.float32)
 lp = torch.log_softmax(torch.from_numpy(z), -1).cuda()
 lm = torch.from_numpy(LanguageModel(os.path.join(ROOT, 'tests/golden/lm_synth45.arpa')).dense_table(synth.phone_table_41(), Cn)).cuda()
 lens = torch.full((B,), T, dtype=torch.int32, device='cuda')
 ids = torch.empty((B, T), dtype=torch.int32, device='cuda'); nids = torch.empty(B, dtype=torch.int32, device='cuda'); st = torch.empty(B, dtype=torch.int32, device='cuda')
-score = torch.zeros(B + B * 10, dtype=torch.float64, device='cuda')   # [B scores | B x 10 int64 stamps]
+score = torch.zeros(B + B * 12, dtype=torch.float64, device='cuda')   # [B scores | B x 12 int64 stamps]
 for _ in range(2):
     _lib.check(_lib.lib().mdd_beam(C.c_void_p(lp.data_ptr()), T, B, Cn, C.c_void_p(lens.data_ptr()), 10, 0, C.c_void_p(lm.data_ptr()), 0.0,
                C.c_void_p(ids.data_ptr()), C.c_void_p(nids.data_ptr()), C.c_void_p(st.data_ptr()), C.c_void_p(score.data_ptr()), None))
 torch.cuda.synchronize()
-ph = score[B:].view(torch.int64).view(B, 10).cpu().numpy().astype(np.float64)
-names = ['load/prefetch', 'candidates', 'copy+parent', 'verify', 'err+merge', 'lmax', 'lane-rank+theta', 'compact', 'rank', '(list len sum)']
-tot = ph[:, :9].sum(1).mean()
+ph = score[B:].view(torch.int64).view(B, 12).cpu().numpy().astype(np.float64)
+names = ['load/prefetch', 'candidates', 'copy+parent', 'verify', 'err', 'merge', 'lmax+lane-rank+theta', 'compact', 'rank', 'materialise', 'prefix copy', '(list len sum)']
+tot = ph[:, :11].sum(1).mean()
 for i, n in enumerate(names):
-    print('%-18s %10.0f cycles/utt  %5.1f%%  (%.0f per frame)' % (n, ph[:, i].mean(), 100 * ph[:, i].mean() / tot, ph[:, i].mean() / T))
+    print('%-22s %10.0f cycles/utt  %5.1f%%  (%.0f per frame)' % (n, ph[:, i].mean(), 100 * ph[:, i].mean() / tot, ph[:, i].mean() / T))
 print('total stamped cycles/utt %.0f' % tot)
