@@ -55,10 +55,12 @@ __global__ __launch_bounds__(256) void greedy_kernel(const float *__restrict__ l
 #define LOG_ZERO (-99999999.0)  // AA/utils/BeamSearch.py:6
 
 __device__ __forceinline__ double log_add_prob(double lx, double ly) {  // BeamSearch.py:43-50
-    if (lx <= LOG_ZERO) return ly;
-    if (ly <= LOG_ZERO) return lx;
-    if ((ly - lx) > 0.0) { double t = lx; lx = ly; ly = t; }
-    return lx + log(1 + exp(ly - lx));
+    // branch-free (every lane evaluates the sum, the early returns are selects): the ~150 fp64 instructions can then be
+    // scheduled among the neighbouring loads instead of sitting behind their own exec-mask branches
+    const bool swap = (ly - lx) > 0.0;
+    const double hi = swap ? ly : lx, lo = swap ? lx : ly;
+    const double sum = hi + log(1 + exp(lo - hi));
+    return lx <= LOG_ZERO ? ly : (ly <= LOG_ZERO ? lx : sum);
 }
 
 struct BeamMeta {       // one entry of `last` (BeamSearch.py:9-15); prefix bytes live in a separate LDS array
@@ -392,12 +394,14 @@ __global__ __launch_bounds__(64) void beam_kernel(const double *__restrict__ lpw
 //   candidates >= theta0 -> rank counting among those (rank < keep IS the output position).
 constexpr int FB = 16;   // max beams on the fast path
 typedef double f64x2 __attribute__((ext_vector_type(2)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
 
 // Workgroup shape: W = blockDim.x / 64 independent waves, one utterance each, sharing only the LM table.  A beam wave
 // holds ~210 VGPRs, so a CU that hosts one cannot take a workgroup of the forward's GEMM (2 x 256 VGPRs per SIMD) or
 // persistent BiLSTM (414): dealt one wave per CU the search would fence the whole chip off from the next batch's
-// forward for its entire duration.  Packed W to a CU (two per SIMD, latency-bound so they interleave for free) it
-// occupies B / W CUs and the forward keeps the rest.  Waves never meet at a workgroup barrier after the LM load
+// forward for its entire duration.  Packed W = 4 to a CU (one per SIMD, each with the full 512-VGPR budget so that a
+// phase's loads can all be in flight) it occupies B / 4 CUs and the forward keeps the rest.  Waves never meet at a workgroup barrier after the LM load
 // (utterance lengths differ); inside a wave, LDS operations complete in order, so a wave-scope fence is the only
 // synchronisation between the phases.
 #define BEAM_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); \
@@ -406,20 +410,29 @@ typedef double f64x2 __attribute__((ext_vector_type(2)));
 // LDS bytes of one wave's private state (NS*64 slots, beam prefixes of up to Tcap ids)
 __host__ __device__ inline size_t beam_fast_wave_bytes(int NS, int beam, int Tcap) {
     return sizeof(double) * ((size_t)2 * NS * 64 + 64 + 6 * FB + 4 * FB) + sizeof(unsigned long long) * 4 * FB +
-           sizeof(int) * ((size_t)2 * NS * 64 + 4 * FB + 3 * FB) + (size_t)(2 * beam + 1) * Tcap;
+           sizeof(int) * ((size_t)2 * NS * 64 + 4 * FB + 2 * FB) + (size_t)(2 * FB + 1) * Tcap;   // FB prefix rows whatever the beam: no row guards
 }
+__host__ __device__ inline size_t beam_fast_lm_bytes(int C) { return (sizeof(double) * (size_t)(C + 1) * (C + 1) + 15) & ~(size_t)15; }
 
+// Coding rules of this kernel (a lone wave pays ~120 cycles per dependent LDS round trip and ~4 cycles per VALU
+// instruction, and the compiler turns every conditional load into a branch with its own wait):
+//   * loads are unconditional, from clamped (always valid) addresses, gathered at the top of a phase; conditions are
+//     applied to registers afterwards; per-beam arrays of FB entries are read whole with 16-byte loads;
+//   * everything wave-uniform (frame counters, beam count, keep, list lengths) is forced into SGPRs with
+//     v_readfirstlane so that the control flow stays scalar;
+//   * per-beam values (copy-path scores, parent, merge slot) stay in the registers of lane == beam and move between
+//     lanes with v_readlane / ballots rather than through LDS.
 template <int NS, bool DBG>
-__global__ __launch_bounds__(NS == 8 ? 512 : 256) void beam_fast_kernel(const double *__restrict__ lpw, const unsigned char *__restrict__ flags,
+__global__ __launch_bounds__(256) void beam_fast_kernel(const double *__restrict__ lpw, const unsigned char *__restrict__ flags,
                                                        int T, int B, int C, const int32_t *__restrict__ len, int beam, int blank,
                                                        const double *__restrict__ lm, double alpha, int32_t *__restrict__ ids,
                                                        int32_t *__restrict__ nids, int32_t *__restrict__ status,
                                                        double *__restrict__ score, int Tcap, long long *__restrict__ dbg) {
     extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
     const int C1 = C + 1;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     double *lmt = reinterpret_cast<double *>(sm);                      // [C1*C1], shared by the waves
-    unsigned char *mine = sm + sizeof(double) * (size_t)C1 * C1 + (size_t)wave * ((beam_fast_wave_bytes(NS, beam, Tcap) + 15) & ~(size_t)15);
+    unsigned char *mine = sm + beam_fast_lm_bytes(C) + (size_t)wave * ((beam_fast_wave_bytes(NS, beam, Tcap) + 15) & ~(size_t)15);
     double *tot = reinterpret_cast<double *>(mine);                    // [NS*64]
     double *cl_v = tot + NS * 64;                                      // [NS*64] compacted candidates: value,
     double *lp = cl_v + NS * 64;                                       // [64]
@@ -430,7 +443,7 @@ __global__ __launch_bounds__(NS == 8 ? 512 : 256) void beam_fast_kernel(const do
     int *cl_o = reinterpret_cast<int *>(m_phash + 2);                  //   insertion order,
     int *cl_x = cl_o + NS * 64;                                        //   slot index
     int (*m_len)[FB] = reinterpret_cast<int (*)[FB]>(cl_x + NS * 64), (*m_last)[FB] = m_len + 2;
-    int *parent = reinterpret_cast<int *>(m_last + 2), *mslot = parent + FB, *sel_x = mslot + FB;
+    int *mslot = reinterpret_cast<int *>(m_last + 2), *sel_x = mslot + FB;
     unsigned char *fl = reinterpret_cast<unsigned char *>(sel_x + FB);
     unsigned char *pref = fl + Tcap;
 
@@ -441,41 +454,49 @@ __global__ __launch_bounds__(NS == 8 ? 512 : 256) void beam_fast_kernel(const do
     int cur = 0, nb = 1, err = 0;
     long long ph[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tstamp = 0;   // MDD_BEAM_DBG: cycles per phase
 #define FSTAMP(i) do { if (DBG) { long long now_ = __builtin_readcyclecounter(); ph[i] += now_ - tstamp; tstamp = now_; } } while (0)
-    if (lane == 0) {
-        m_T[0][0] = 0.0; m_B[0][0] = 0.0; m_NB[0][0] = LOG_ZERO; m_len[0][0] = 0; m_last[0][0] = -1;
-        m_hash[0][0] = 0x243F6A8885A308D3ull; m_phash[0][0] = 0;
+    if (lane < FB) {   // beam 0 = the empty prefix; the other entries only need to be valid numbers
+        m_T[0][lane] = 0.0; m_B[0][lane] = 0.0; m_NB[0][lane] = LOG_ZERO; m_len[0][lane] = lane == 0 ? 0 : -2; m_last[0][lane] = -1;
+        m_hash[0][lane] = 0x243F6A8885A308D3ull; m_phash[0][lane] = 0;
+        m_T[1][lane] = 0.0; m_B[1][lane] = 0.0; m_NB[1][lane] = LOG_ZERO; m_len[1][lane] = 0; m_last[1][lane] = -1;
+        m_hash[1][lane] = 0; m_phash[1][lane] = 0;
+        mslot[lane] = -1; sel_x[lane] = 0; sel_v[lane] = 0.0; cNB[lane] = 0.0; cB[lane] = 0.0;
     }
-    int tl = len[b];
+    int tl = __builtin_amdgcn_readfirstlane(len[b]);
     tl = tl < 0 ? 0 : (tl > T ? T : tl);
     for (int i = lane; i < tl; i += 64) fl[i] = flags[(size_t)i * B + b];
     // slot coordinates of this lane (constant over the whole utterance): slot = lane + 64 i = r*C + k
-    int sr[NS], sk[NS], so[NS];
+    // (kept as data, not as hoisted lane masks: a dozen loop-invariant 64-bit masks cost more SGPRs than the wave has)
+    int sr[NS], sk[NS], sx[NS];                                        // sx: the slot index, or a huge one for copy slots (k == blank)
 #pragma unroll
     for (int i = 0; i < NS; i++) {
         const int idx = lane + 64 * i;
         sr[i] = idx / C; sk[i] = idx - sr[i] * C;
-        so[i] = sr[i] * C + (sk[i] == blank ? 0 : (sk[i] < blank ? sk[i] + 1 : sk[i]));   // insertion order of the slot
+        sx[i] = sk[i] == blank ? 0x7fffffff : idx;
     }
     const float invC = 1.0f / (float)C;
+    const int nw = Tcap >> 2;                                          // words per prefix row
+    const int li = lane & (FB - 1);                                    // the beam this lane speaks for (lanes >= FB: a valid alias)
     BEAM_WAVE_SYNC();
 
     int t = 0;
-    while (t < tl && !(fl[t] & 1)) t++;
+    while (t < tl && !(__builtin_amdgcn_readfirstlane(fl[t]) & 1)) t++;
     double pre = (t < tl && lane < C) ? lpw[((size_t)t * B + b) * C + lane] : 0.0;
     if (DBG) tstamp = __builtin_readcyclecounter();
     while (t < tl) {
-        const bool rep_ok = (fl[t] & 2) != 0;
+        const bool rep_ok = (__builtin_amdgcn_readfirstlane(fl[t]) & 2) != 0;
         if (lane < C) lp[lane] = pre;
         int tn = t + 1;
-        while (tn < tl && !(fl[tn] & 1)) tn++;
+        while (tn < tl && !(__builtin_amdgcn_readfirstlane(fl[tn]) & 1)) tn++;
         pre = (tn < tl && lane < C) ? lpw[((size_t)tn * B + b) * C + lane] : 0.0;
         BEAM_WAVE_SYNC();
-        unsigned char *pcur = pref + (size_t)cur * beam * Tcap, *pnext = pref + (size_t)(cur ^ 1) * beam * Tcap;
+        const unsigned int *srcw = reinterpret_cast<const unsigned int *>(pref + (size_t)cur * FB * Tcap);
+        unsigned char *pnext = pref + (size_t)(cur ^ 1) * FB * Tcap;
         const int nslot = nb * C;
 
         FSTAMP(0);
-        // ---- candidate scores: gather every operand first (independent LDS reads), then store
-        int first_err_ord = 0x7fffffff, first_err = 0;
+        // ---- candidate scores (BeamSearch.py:53-69): gather every operand, then store.  errp = (order << 2 | kind) of
+        // the first failure in the reference's execution order (kind 1: LM KeyError, 2: log(0) ValueError)
+        int errp = 0x7fffffff;
         double val[NS];
 #pragma unroll
         for (int i = 0; i < NS; i++) {
@@ -484,89 +505,98 @@ __global__ __launch_bounds__(NS == 8 ? 512 : 256) void beam_fast_kernel(const do
             const double yB = m_B[cur][r], yT = m_T[cur][r];
             const double lmv = lmt[(ylen ? ylast : C) * C1 + k];   // consulted even when alpha == 0 (BeamSearch.py:57-60)
             const double lk = lp[k];
-            const bool live = lane + 64 * i < nslot && k != blank;
-            if (live) {
-                const int ord = sr[i] * C1 + 1 + k;
-                if (lmv != lmv) { if (ord < first_err_ord) { first_err_ord = ord; first_err = MDD_BEAM_KEY_ERROR; } }
-                else if (lk == -INFINITY) { if (ord < first_err_ord) { first_err_ord = ord; first_err = MDD_BEAM_VALUE_ERROR; } }
-            }
+            const bool live = sx[i] < nslot;                             // an extension slot of a beam that exists
+            const int kind = (lmv != lmv) ? 1 : ((lk == -INFINITY) ? 2 : 0);
+            const int e = (live && kind) ? (((sr[i] * C1 + 1 + k) << 2) | kind) : 0x7fffffff;
+            errp = min(errp, e);
             const double base = (ylen && ylast == k && rep_ok) ? yB : yT;   // :63-66
             val[i] = live ? lk + lmv * alpha + base : -INFINITY;
         }
 #pragma unroll
-        for (int i = 0; i < NS; i++)
-            if (sk[i] != blank || lane + 64 * i >= nslot) tot[lane + 64 * i] = val[i];   // copy slots are written below
+        for (int i = 0; i < NS; i++) tot[lane + 64 * i] = val[i];        // copy slots (k == blank) are overwritten just below
         FSTAMP(1);
-        // ---- copy path of beam `lane` (:101-113) and its parent candidate
-        if (lane < nb) {
-            const int ylen = m_len[cur][lane], ylast = m_last[cur][lane];
-            double pnb = LOG_ZERO;
-            const double lpb = lp[blank];
-            bool bad = (lpb == -INFINITY);
-            if (ylen > 0) { const double lpl = lp[ylast]; pnb = m_NB[cur][lane] + lpl; bad = bad || (lpl == -INFINITY); }
-            const double pb = m_T[cur][lane] + lpb;
-            if (bad) { const int ord = lane * C1; if (ord < first_err_ord) { first_err_ord = ord; first_err = MDD_BEAM_VALUE_ERROR; } }
-            cNB[lane] = pnb; cB[lane] = pb;
-            const double tc = log_add_prob(pb, pnb);
-            cT[lane] = tc;
-            tot[lane * C + blank] = tc;
-            int par = -1;
-            const unsigned long long myph = m_phash[cur][lane];
+        // ---- copy path of beam `li` (:101-113), and the beam (if any) that holds its prefix minus the last id
+        const int ylen = m_len[cur][li], ylast = m_last[cur][li];
+        double pnb, pb, tc;
+        int par = -1;
+        {
+            const double lpb = lp[blank], lpl = lp[max(ylast, 0)];
+            const double mNB = m_NB[cur][li], mT = m_T[cur][li];
+            const unsigned long long myph = m_phash[cur][li];
+            i32x4 L4[FB / 4];
+            u64x2 H2[FB / 2];
 #pragma unroll
-            for (int q = 0; q < FB; q++)
-                if (q < nb && par < 0 && q != lane && ylen > 0 && m_len[cur][q] == ylen - 1 && m_hash[cur][q] == myph) par = q;
-            parent[lane] = par;
-            mslot[lane] = -1;
+            for (int q = 0; q < FB / 4; q++) L4[q] = reinterpret_cast<const i32x4 *>(m_len[cur])[q];
+#pragma unroll
+            for (int q = 0; q < FB / 2; q++) H2[q] = reinterpret_cast<const u64x2 *>(m_hash[cur])[q];
+            pnb = ylen > 0 ? mNB + lpl : LOG_ZERO;
+            pb = mT + lpb;
+            const bool bad = lpb == -INFINITY || (ylen > 0 && lpl == -INFINITY);
+            if (lane < nb && bad) errp = min(errp, ((lane * C1) << 2) | 2);
+            tc = log_add_prob(pb, pnb);
+#pragma unroll
+            for (int q = FB - 1; q >= 0; q--) {                          // the lowest matching q wins
+                const bool hit = L4[q >> 2][q & 3] == ylen - 1 && H2[q >> 1][q & 1] == myph;   // entries >= nb hold length -2
+                par = hit ? q : par;
+            }
+            par = (lane < nb && ylen > 0) ? par : -1;
+            if (lane < nb) tot[lane * C + blank] = tc;
         }
         FSTAMP(2);
-        // verify the content of every hash match with the whole wave (never merge on a hash collision)
-        for (int a = 0; a < nb; a++) {
-            const int q = parent[a];
-            if (q < 0) continue;
-            const int ln = m_len[cur][q];
-            const unsigned int *wa = reinterpret_cast<const unsigned int *>(pcur + (size_t)a * Tcap);
-            const unsigned int *wq = reinterpret_cast<const unsigned int *>(pcur + (size_t)q * Tcap);
-            bool neq = false;
-            for (int j = lane; j * 4 < ln; j += 64) {
-                unsigned int x = wa[j] ^ wq[j];
-                const int rem = ln - j * 4;
-                if (rem < 4) x &= (1u << (8 * rem)) - 1u;
-                neq = neq || (x != 0);
+        // verify the content of every hash match with the whole wave (never merge on a hash collision): all pairs at once
+        {
+            const unsigned int pm = (unsigned int)__ballot(par >= 0);    // beams with a parent candidate (bits < FB)
+            if (pm) {
+                unsigned int neq = 0;
+                for (int j0 = 0; j0 < nw; j0 += 64) {
+                    const int j = min(j0 + lane, nw - 1);
+                    unsigned int wa[FB], wq[FB];
+#pragma unroll
+                    for (int a = 0; a < FB; a++) {
+                        const int qa = max(__builtin_amdgcn_readlane(par, a), 0);
+                        wa[a] = srcw[a * nw + j];
+                        wq[a] = srcw[qa * nw + j];
+                    }
+#pragma unroll
+                    for (int a = 0; a < FB; a++) {
+                        const int rem = __builtin_amdgcn_readlane(ylen, a) - 1 - 4 * j;      // bytes of the parent's prefix from word j on
+                        const unsigned int m = rem >= 4 ? 0xffffffffu : (rem <= 0 ? 0u : ((1u << (8 * rem)) - 1u));
+                        neq |= (((wa[a] ^ wq[a]) & m) != 0 ? 1u : 0u) << a;
+                    }
+                }
+                unsigned int bad = 0;
+#pragma unroll
+                for (int a = 0; a < FB; a++) bad |= (__any((neq >> a) & 1) ? 1u : 0u) << a;
+                if ((bad >> li) & 1) par = -1;
             }
-            if (__any(neq) && lane == 0) parent[a] = -1;
         }
         FSTAMP(3);
-        {   // first error in the reference's execution order wins
-            int eo = first_err_ord;
+        if (__any(errp != 0x7fffffff)) {   // first error in the reference's execution order wins
+            int eo = errp;
             for (int o = 32; o > 0; o >>= 1) eo = min(eo, __shfl_xor(eo, o));
-            if (eo != 0x7fffffff) {
-                const unsigned long long who = __ballot(first_err_ord == eo);
-                err = __shfl(first_err, __ffsll((long long)who) - 1);
-                break;
-            }
+            err = (eo & 3) == 1 ? MDD_BEAM_KEY_ERROR : MDD_BEAM_VALUE_ERROR;
+            break;
         }
         BEAM_WAVE_SYNC();
         FSTAMP(4);
-        // ---- merges (see beam_kernel)
-        int nmerge = 0;
-        if (lane < nb && parent[lane] >= 0) {
-            const int a = lane, q = parent[a], e = q * C + m_last[cur][a];
+        // ---- merges (see beam_kernel): a beam whose prefix is also reachable as parent + last id takes both paths
+        int ms = -1;
+        const bool merging = par >= 0;
+        const int nmerge = __popcll(__ballot(merging));
+        if (nmerge) {
+            const int q = max(par, 0), e = q * C + max(ylast, 0);
             const double pr = tot[e];
-            if (q < a) {
-                cNB[a] = log_add_prob(pr, cNB[a]);
-                cT[a] = log_add_prob(pr, cT[a]);
-                tot[e] = cT[a];
-                tot[a * C + blank] = -INFINITY;
-                mslot[a] = e;
-            } else {
-                cNB[a] = log_add_prob(cNB[a], pr);
-                cT[a] = log_add_prob(cT[a], pr);
-                tot[a * C + blank] = cT[a];
-                tot[e] = -INFINITY;
+            const bool fwd = q < lane;                                    // the extension was inserted before the copy
+            const double nNB = log_add_prob(fwd ? pr : pnb, fwd ? pnb : pr);
+            const double nT = log_add_prob(fwd ? pr : tc, fwd ? tc : pr);
+            if (merging) {
+                pnb = nNB; tc = nT;
+                tot[fwd ? e : lane * C + blank] = nT;
+                tot[fwd ? lane * C + blank : e] = -INFINITY;
+                ms = fwd ? e : -1;
             }
-            nmerge = 1;
         }
-        nmerge = __popcll(__ballot(nmerge != 0));
+        if (lane < FB) { cNB[lane] = pnb; cB[lane] = pb; mslot[lane] = lane < nb ? ms : -1; }
         BEAM_WAVE_SYNC();
         FSTAMP(5);
         // ---- top-`keep` selection
@@ -583,10 +613,15 @@ __global__ __launch_bounds__(NS == 8 ? 512 : 256) void beam_fast_kernel(const do
         cl_v[lane] = lmax;
         BEAM_WAVE_SYNC();
         int rk = 0;
-#pragma unroll 8
-        for (int j = 0; j < 64; j += 2) {
-            const f64x2 sj = *reinterpret_cast<const f64x2 *>(cl_v + j);
-            rk += (sj.x > lmax ? 1 : 0) + (sj.y > lmax ? 1 : 0);
+#pragma unroll
+        for (int h = 0; h < 2; h++) {   // two rounds of 16 reads, all of a round in flight before the first compare
+            f64x2 sj[16];
+#pragma unroll
+            for (int j = 0; j < 16; j++) sj[j] = reinterpret_cast<const f64x2 *>(cl_v)[16 * h + j];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < 16; j++) rk += (sj[j].x > lmax ? 1 : 0) + (sj[j].y > lmax ? 1 : 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
         unsigned long long mk = 0;
         for (int r = keep - 1; r >= 0 && mk == 0; r--) mk = __ballot(rk == r);
@@ -599,13 +634,16 @@ __global__ __launch_bounds__(NS == 8 ? 512 : 256) void beam_fast_kernel(const do
         const unsigned long long lt = (1ull << lane) - 1ull;
 #pragma unroll
         for (int i = 0; i < NS; i++) {
-            const bool pred = tv[i] >= theta0 && lane + 64 * i < nslot;
+            const bool pred = tv[i] >= theta0;                           // theta0 is finite, slots >= nslot hold -inf
             const unsigned long long msk = __ballot(pred);
-            if (pred) {
-                const int pos = nl + __popcll(msk & lt);
-                cl_v[pos] = tv[i]; cl_o[pos] = so[i]; cl_x[pos] = lane + 64 * i;
+            if (msk) {
+                if (pred) {
+                    const int pos = nl + __popcll(msk & lt), k = sk[i];
+                    cl_v[pos] = tv[i]; cl_x[pos] = lane + 64 * i;
+                    cl_o[pos] = sr[i] * C + (k == blank ? 0 : (k < blank ? k + 1 : k));   // insertion order of the slot
+                }
+                nl += __popcll(msk);
             }
-            nl += __popcll(msk);
         }
         BEAM_WAVE_SYNC();
         FSTAMP(7);
@@ -639,44 +677,50 @@ __global__ __launch_bounds__(NS == 8 ? 512 : 256) void beam_fast_kernel(const do
         BEAM_WAVE_SYNC();
         FSTAMP(8);
         if (DBG) ph[11] += nl;
-        // ---- materialise the new beams
+        // ---- materialise new beam `li` (lanes >= keep compute on stale but valid entries and store nothing)
         const int nxt = cur ^ 1;
-        int app_k = -1, app_at = 0;                                       // id appended to new beam `lane`, and where
-        if (lane < keep) {
-            const int idx = sel_x[lane];
-            const int r = (int)(((float)idx + 0.5f) * invC), k = idx - r * C;
-            const double v = sel_v[lane];
-            if (k == blank) {
-                m_T[nxt][lane] = v; m_NB[nxt][lane] = cNB[r]; m_B[nxt][lane] = cB[r];
-                m_len[nxt][lane] = m_len[cur][r]; m_last[nxt][lane] = m_last[cur][r];
-                m_hash[nxt][lane] = m_hash[cur][r]; m_phash[nxt][lane] = m_phash[cur][r];
-            } else {
-                double nbv = v, bv = LOG_ZERO;
+        int r_new, app_k, app_at;                                         // parent row; id appended (-1: none) and where
+        {
+            const int idx = sel_x[li];
+            const double v = sel_v[li];
+            i32x4 M4[FB / 4];
 #pragma unroll
-                for (int a = 0; a < FB; a++)
-                    if (a < nb && mslot[a] == idx) { nbv = cNB[a]; bv = cB[a]; }
-                const unsigned long long h = m_hash[cur][r];
-                m_T[nxt][lane] = v; m_NB[nxt][lane] = nbv; m_B[nxt][lane] = bv;
-                app_at = m_len[cur][r]; app_k = k;
-                m_len[nxt][lane] = app_at + 1; m_last[nxt][lane] = k;
-                m_phash[nxt][lane] = h; m_hash[nxt][lane] = h * 0x9E3779B97F4A7C15ull + (unsigned long long)(k + 1);
+            for (int a = 0; a < FB / 4; a++) M4[a] = reinterpret_cast<const i32x4 *>(mslot)[a];
+            const int r = min((int)(((float)idx + 0.5f) * invC), FB - 1), k = idx - r * C;
+            const double cNBr = cNB[r], cBr = cB[r];
+            const int len_r = m_len[cur][r], last_r = m_last[cur][r];
+            const unsigned long long hash_r = m_hash[cur][r], phash_r = m_phash[cur][r];
+            int fa = -1;                                                  // the beam merged into this extension, if any
+#pragma unroll
+            for (int a = 0; a < FB; a++) fa = M4[a >> 2][a & 3] == idx ? a : fa;   // entries >= nb hold -1
+            const double cNBa = cNB[max(fa, 0)], cBa = cB[max(fa, 0)];
+            const bool isb = k == blank;
+            r_new = r; app_k = isb ? -1 : k; app_at = len_r;
+            if (lane < FB) {   // entries keep..FB-1 get length -2: no prefix is their child (parent search above)
+                const bool on = lane < keep;
+                m_T[nxt][lane] = v;
+                m_NB[nxt][lane] = isb ? cNBr : (fa >= 0 ? cNBa : v);
+                m_B[nxt][lane] = isb ? cBr : (fa >= 0 ? cBa : LOG_ZERO);
+                m_len[nxt][lane] = on ? (isb ? len_r : len_r + 1) : -2;
+                m_last[nxt][lane] = on ? (isb ? last_r : k) : -1;
+                m_hash[nxt][lane] = isb ? hash_r : hash_r * 0x9E3779B97F4A7C15ull + (unsigned long long)(k + 1);
+                m_phash[nxt][lane] = isb ? phash_r : hash_r;
             }
         }
         FSTAMP(9);
         {   // prefixes: every new beam copies its parent's whole row (bytes past a prefix's length are never read),
             // one word per lane and row, all rows in flight together; the appended id goes in afterwards
+            // (rows keep..FB-1 receive a copy of some valid row: harmless, and it keeps every load and store unconditional)
             int rr[FB];
 #pragma unroll
-            for (int i = 0; i < FB; i++) rr[i] = (int)(((float)sel_x[i < keep ? i : keep - 1] + 0.5f) * invC);
-            const int nw = Tcap >> 2;
-            const unsigned int *srcw = reinterpret_cast<const unsigned int *>(pcur);
+            for (int i = 0; i < FB; i++) rr[i] = __builtin_amdgcn_readlane(r_new, i);
             unsigned int *dstw = reinterpret_cast<unsigned int *>(pnext);
             for (int j = lane; j < nw; j += 64) {
                 unsigned int w[FB];
 #pragma unroll
                 for (int i = 0; i < FB; i++) w[i] = srcw[rr[i] * nw + j];
 #pragma unroll
-                for (int i = 0; i < FB; i++) if (i < keep) dstw[i * nw + j] = w[i];
+                for (int i = 0; i < FB; i++) dstw[i * nw + j] = w[i];
             }
             BEAM_WAVE_SYNC();
             if (lane < keep && app_k >= 0) pnext[(size_t)lane * Tcap + app_at] = (unsigned char)app_k;
@@ -704,7 +748,7 @@ __global__ __launch_bounds__(NS == 8 ? 512 : 256) void beam_fast_kernel(const do
         int n = 0;
         if (!err && best >= 0) {
             n = m_len[cur][best];
-            const unsigned char *src = pref + (size_t)cur * beam * Tcap + (size_t)best * Tcap;
+            const unsigned char *src = pref + (size_t)cur * FB * Tcap + (size_t)best * Tcap;
             for (int j = 0; j < n; j++) ids[(size_t)b * T + j] = src[j];
         }
         nids[b] = n;
@@ -761,7 +805,7 @@ extern "C" int mdd_beam(const float *logp_dev, int32_t T, int32_t B, int32_t C, 
     const int nslots = beam * C;
     if (beam <= FB && C <= 64 && nslots <= 1024 && !getenv("MDD_BEAM_GENERIC")) {
         const int NS = nslots <= 512 ? 8 : 16;
-        const size_t lmb = sizeof(double) * (size_t)(C + 1) * (C + 1);
+        const size_t lmb = beam_fast_lm_bytes(C);
         const size_t pw = (beam_fast_wave_bytes(NS, beam, Tcap) + 15) & ~(size_t)15;
         const size_t lds_max = 160 * 1024;
         static bool fattr = false;
@@ -773,11 +817,10 @@ extern "C" int mdd_beam(const float *logp_dev, int32_t T, int32_t B, int32_t C, 
             fattr = true;
         }
         if (lmb + pw > lds_max) { (void)hipFreeAsync(lpw, st); set_error("mdd_beam: T too long for LDS (%zu B)", lmb + pw); return MDD_ERR_ARG; }
-        // waves per workgroup: as many as the LDS holds (<= 8); a small batch spreads out instead (one wave per CU is the
+        // waves per workgroup: as many as the LDS holds (<= 4); a small batch spreads out instead (one wave per CU is the
         // lowest latency when nothing else wants the CUs)
         int W = (int)((lds_max - lmb) / pw);
-        W = W > 8 ? 8 : W;
-        if (NS == 16 && W > 4) W = 4;                                   // the 1024-slot variant needs > 256 VGPRs
+        W = W > 4 ? 4 : W;                                              // one wave per SIMD: the kernel is built for the 512-VGPR budget
         if (B <= 64) W = 1;
         if (const char *we = getenv("MDD_BEAM_W")) { const int w = atoi(we); if (w >= 1 && w <= W) W = w; }
         const size_t fs = lmb + (size_t)W * pw;
