@@ -166,6 +166,14 @@ __global__ __launch_bounds__(256, 1) void lstm_step_packed_kernel(LstmStepArgs a
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
+// The recurrent state as split bf16: hi = bf16(h), lo = bf16(h - hi) with its last mantissa bit cleared.  Every
+// recurrent kernel (per-step and persistent) uses this same split, so they stay bit-identical; the cleared bit is where
+// the granule hand-off carries its epoch tag (h keeps ~16 significant bits: 2^-17 relative).
+__device__ __forceinline__ unsigned int split_h(float hn) {          // returns hi | lo << 16
+    __bf16 hb = (__bf16)hn, lbf = (__bf16)(hn - (float)hb);
+    return (unsigned int)*reinterpret_cast<unsigned short *>(&hb) | (((unsigned int)*reinterpret_cast<unsigned short *>(&lbf) & 0xfffeu) << 16);
+}
+
 template <int RT, int H>
 __global__ __launch_bounds__(256, 1) void lstm_step_x3_kernel(LstmStepArgs a, int s) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -254,9 +262,9 @@ __global__ __launch_bounds__(256, 1) void lstm_step_x3_kernel(LstmStepArgs a, in
         const float hn = og * fast_tanh(cn);
         a.cbuf[ci] = cn;
         {
-            __bf16 hb = (__bf16)hn, lb = (__bf16)(hn - (float)hb);
-            hnext_h[(size_t)b * H + u] = *reinterpret_cast<unsigned short *>(&hb);
-            hnext_l[(size_t)b * H + u] = *reinterpret_cast<unsigned short *>(&lb);
+            const unsigned int pk = split_h(hn);
+            hnext_h[(size_t)b * H + u] = (unsigned short)(pk & 0xffffu);
+            hnext_l[(size_t)b * H + u] = (unsigned short)(pk >> 16);
         }
         const size_t oi = ((size_t)t * B + b) * 2 * H + d * H + u;
         if (a.out_raw) a.out_raw[oi] = hn;
@@ -312,9 +320,11 @@ struct PersistArgs {
     const float *oscale, *oshift;
     int T, B, BG, BGr;               // BG: padded rows per group (multiple of 16), BGr: real rows per group
     long long *dbg;                  // diagnostic builds only: per-workgroup cycle sums of the step phases (null in production)
+    int exp;                         // MDD_LSTM_EXP: experiment bits (0 in production)
 };
 
 typedef unsigned long long u64;
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ u64 ld_agent(const u64 *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void st_agent(u64 *p, u64 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
@@ -442,10 +452,8 @@ __global__ __launch_bounds__(H / 64 * 64, 1) void lstm_layer_persistent_kernel(P
             const float hn = valid ? og * fast_tanh(cn) : 0.f;
             cst[bt] = cn;
             hcur[bt] = hn;
-            __bf16 hb = (__bf16)hn, lbf = (__bf16)(hn - (float)hb);
-            const unsigned int hbits = *reinterpret_cast<unsigned short *>(&hb), lbits = *reinterpret_cast<unsigned short *>(&lbf);
             // gather the 4 units of this row tile (lanes li, li+16, li+32, li+48) into one 8-byte granule per plane
-            const unsigned int pk = hbits | (lbits << 16);
+            const unsigned int pk = split_h(hn);
             const unsigned int p1 = __shfl(pk, li + 16), p2 = __shfl(pk, li + 32), p3 = __shfl(pk, li + 48);
             if (kq == 0) {
                 const u64 hi4 = (u64)(pk & 0xffffu) | ((u64)(p1 & 0xffffu) << 16) | ((u64)(p2 & 0xffffu) << 32) | ((u64)(p3 & 0xffffu) << 48);
@@ -483,19 +491,34 @@ __global__ __launch_bounds__(H / 64 * 64, 1) void lstm_layer_persistent_kernel(P
     if (a.dbg && tid == 0) for (int i = 0; i < 6; i++) a.dbg[blockIdx.x * 6 + i] = ph[i];
 }
 
+// acc += A.B with A taken straight from an accumulation-file register (half of the resident weight fragments live
+// there: the compiler would otherwise copy each one to a VGPR with four v_accvgpr_read per MFMA, on every step)
+__device__ __forceinline__ void mfma_a(f32x4 &acc, const bf16x8 &a_agpr, const bf16x8 &b) {
+    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc) : "a"(a_agpr), "v"(b));
+}
+
 // ---- persistent layer kernel, data-tagged hand-off ("the data IS the flag", Guideline 16 form R2).
 // Same team structure, but (1) a team is 8 workgroups (32 teams = 2 directions x 16 batch groups), each workgroup
 // owning 4H/8 gate rows: RTW row tiles per wave, fragments resident in registers; the panel a workgroup pulls per
-// step is half as tall; (2) h travels as 8-byte granules {tag = step+1, bf16 hi | bf16 lo}: the producer just
+// step is half as tall; (2) h travels as 8-byte granules of TWO units {hi0 | lo0 << 16, hi1 | lo1 << 16} whose epoch
+// tag (1..3 = step % 3 + 1) rides in the two spare last bits of lo0 and lo1 (split_h clears them): the producer just
 // stores them write-through -- no drain, no barrier, no counter -- and the consumer re-reads its share of the panel
-// until every tag equals the epoch.  One L2 round trip replaces three (drain, counter add, poll).  The exchange
-// buffer is zeroed before every launch (tags are never 0), so replays cannot see a previous launch's tags.
+// until every tag equals the epoch.  One L2 round trip replaces three (drain, counter add, poll).  A panel of one
+// parity only ever holds step s or step s-2 (nobody publishes step s before everyone has read s-2), whose tags
+// differ; the exchange buffer is zeroed before every launch (tag 0 is never valid), so replays cannot see a previous
+// launch's data.  The sweep is bound by the bytes all 256 workgroups pull past their L2s (measured: ~110 cycles per
+// KB of panel), hence the dense format: 4 bytes per unit and row, and only the team's real batch rows.
 template <int H, int NBT, int RTW>
 __global__ __launch_bounds__(256, 1) void lstm_layer_granule_kernel(PersistArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int NTH = 256, KS = H / 32, ROWB = H * 2 + 16, RM = 4 * H / 8, BGC = NBT * 16;
     static_assert(RM == 4 * RTW * 16, "4 waves x RTW row tiles must cover the workgroup's gate rows");
     unsigned char *Ph = smem, *Pl = smem + (size_t)BGC * ROWB;
+    constexpr int UW = RM / 4;                                      // units this workgroup owns (a 2*UW-byte run per output row and plane)
+    unsigned short *Oh = reinterpret_cast<unsigned short *>(smem + (size_t)2 * BGC * ROWB), *Ol = Oh + BGC * UW;   // step outputs, [row][unit]
+    float *Of = reinterpret_cast<float *>(Ol + BGC * UW);
+    unsigned int *Og = reinterpret_cast<unsigned int *>(Of + BGC * UW);   // this step's h as tagged words, [row][unit]
+    static_assert(UW % 8 == 0, "output rows must be whole 16-byte chunks");
     __shared__ int s_fail;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, kq = lane >> 4;
@@ -527,24 +550,60 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_granule_kernel(PersistArgs 
     for (int rt = 0; rt < RTW; rt++)
 #pragma unroll
         for (int bt = 0; bt < NBT; bt++) cst[rt][bt] = 0.f;
-    const size_t pgran = (size_t)BGC * H;                          // granules per (parity, team) panel
+    const size_t pgran = (size_t)BGC * H / 2;                      // granules per (parity, team) panel: [row][unit pair]
+    // rows past the team's real batch rows are never published nor swept: their panel rows stay zero
+    constexpr int NLD0 = BGC * H / 4 / NTH;
+    unsigned need0 = 0;
+#pragma unroll
+    for (int i = 0; i < NLD0; i++) need0 |= ((4 * (tid + NTH * i)) / H < a.BGr ? 1u : 0u) << i;
+    for (int i = tid; i < 2 * BGC * ROWB / 4; i += NTH) reinterpret_cast<unsigned int *>(smem)[i] = 0u;
     u64 *hxg = reinterpret_cast<u64 *>(a.hx);
     unsigned int *abortf = a.sync + 16;
     long long ph[6] = {0, 0, 0, 0, 0, 0}, tst = a.dbg ? (long long)__builtin_readcyclecounter() : 0;
     __syncthreads();
 
-    for (int s = 0; s < T; s++) {
-        const int t = d ? (T - 1 - s) : s;
-        float4 g4[RTW][NBT];
+    // A step's critical path is sweep-complete -> MFMA -> cell -> publish; whatever else a step must issue (the layer
+    // outputs, the next gate pre-activations) goes between the publish and the next sweep, where the workgroup would
+    // only be waiting for its team anyway (placed after the sweep they cost their full issue time on every step).
+    float4 g4[RTW][NBT], g4n[RTW][NBT];
+    auto load_gx = [&](float4 (&dstg)[RTW][NBT], int tt) {
 #pragma unroll
         for (int rt = 0; rt < RTW; rt++)
 #pragma unroll
             for (int bt = 0; bt < NBT; bt++) {
                 const int lb = bt * 16 + li, b = g * a.BGr + lb;
                 const bool valid = lb < a.BGr && b < B;
-                g4[rt][bt] = valid ? *reinterpret_cast<const float4 *>(a.gx + (((size_t)t * B + b) * 2 + d) * 4 * H + unit[rt] * 4)
-                                   : make_float4(0.f, 0.f, 0.f, 0.f);
+                dstg[rt][bt] = valid ? *reinterpret_cast<const float4 *>(a.gx + (((size_t)tt * B + b) * 2 + d) * 4 * H + unit[rt] * 4)
+                                     : make_float4(0.f, 0.f, 0.f, 0.f);
             }
+    };
+    // Layer outputs leave through an LDS tile: the cell update drops its (row, unit) values there, and after the next
+    // barrier the workgroup writes each output row's run as 16-byte chunks (a lane-per-unit store would be 2-byte
+    // pieces over 16 rows: ~24 issue-bound store instructions per step instead of 3).
+    auto store_out = [&](int tt) {
+        constexpr int CH = UW / 8, CF = UW / 4;                       // 16-byte chunks per row: bf16 planes, fp32
+        if (a.out_split.hi) {
+            for (int q = tid; q < 2 * BGC * CH; q += NTH) {
+                const int pl = q >= BGC * CH, qq = pl ? q - BGC * CH : q, lb = qq / CH, c = qq - lb * CH, b = g * a.BGr + lb;
+                if (lb < a.BGr && b < B) {
+                    const u32x4 v = *reinterpret_cast<const u32x4 *>((pl ? Ol : Oh) + lb * UW + c * 8);
+                    *reinterpret_cast<u32x4 *>((pl ? a.out_split.lo : a.out_split.hi) + ((size_t)tt * B + b) * 2 * H + d * H + member * UW + c * 8) = v;
+                }
+            }
+        }
+        if (a.out_raw) {
+            for (int q = tid; q < BGC * CF; q += NTH) {
+                const int lb = q / CF, c = q - lb * CF, b = g * a.BGr + lb;
+                if (lb < a.BGr && b < B)
+                    *reinterpret_cast<u32x4 *>(a.out_raw + ((size_t)tt * B + b) * 2 * H + d * H + member * UW + c * 4) =
+                        *reinterpret_cast<const u32x4 *>(Of + lb * UW + c * 4);
+            }
+        }
+    };
+    load_gx(g4, d ? (T - 1) : 0);
+    if (T > 1) load_gx(g4n, d ? (T - 2) : 1);
+    for (int s = 0; s < T; s++) {
+        const int t = d ? (T - 1 - s) : s;
         f32x4 acc[RTW][NBT];
 #pragma unroll
         for (int rt = 0; rt < RTW; rt++)
@@ -554,27 +613,36 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_granule_kernel(PersistArgs 
             // ---- sweep this thread's share of the team's panel (parity (s-1)&1) until every tag == s
             const u64 *srcp = hxg + (size_t)(((s - 1) & 1) * 32 + team) * pgran;
             const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<u64 *>(srcp), 0, (int)(pgran * 8), 0x00020000);
-            constexpr int NLD = BGC * H / 2 / NTH;                  // 16-byte chunks (2 granules) per thread
-            static_assert(BGC * H / 2 % NTH == 0, "panel must be whole passes of the workgroup");
-            unsigned need = (1u << NLD) - 1u;
-            const unsigned epoch = (unsigned)s;
+            constexpr int NLD = BGC * H / 4 / NTH;                  // 16-byte chunks (2 granules = 4 units) per thread
+            static_assert(BGC * H / 4 % NTH == 0 && H % 4 == 0, "panel must be whole passes of the workgroup");
+            unsigned need = need0;
+            const unsigned ep = (unsigned)((s - 1) % 3 + 1), e0 = (ep & 1u) << 16, e1 = (ep >> 1) << 16;   // tag of step s-1
             int sweeps = 0;
             const long long t0 = wall_clock64();
+            bool first = true;
             while (true) {
                 u32x4 pv[NLD];
 #pragma unroll
                 for (int i = 0; i < NLD; i++)
                     if (need & (1u << i)) pv[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (tid + NTH * i) * 16, 0, 16 /* sc1 */);
+                if (first) { store_out(d ? (T - s) : (s - 1)); first = false; }   // step s-1's outputs, behind the sweep in the queue
 #pragma unroll
                 for (int i = 0; i < NLD; i++)
-                    if ((need & (1u << i)) && pv[i][0] == epoch && pv[i][2] == epoch) {
+                    if ((need & (1u << i)) && (pv[i][0] & 0x10000u) == e0 && (pv[i][1] & 0x10000u) == e1 &&
+                        (pv[i][2] & 0x10000u) == e0 && (pv[i][3] & 0x10000u) == e1) {
                         need &= ~(1u << i);
-                        const int q = tid + NTH * i, row = (2 * q) / H, k = 2 * q - row * H;
-                        *reinterpret_cast<unsigned int *>(Ph + row * ROWB + k * 2) = (pv[i][1] & 0xffffu) | (pv[i][3] << 16);
-                        *reinterpret_cast<unsigned int *>(Pl + row * ROWB + k * 2) = (pv[i][1] >> 16) | (pv[i][3] & 0xffff0000u);
+                        const int q = tid + NTH * i, row = (4 * q) / H, k = 4 * q - row * H;
+                        u32x2 vh, vl;
+                        vh[0] = (pv[i][0] & 0xffffu) | (pv[i][1] << 16); vh[1] = (pv[i][2] & 0xffffu) | (pv[i][3] << 16);
+                        vl[0] = ((pv[i][0] >> 16) & 0xfffeu) | (pv[i][1] & 0xfffe0000u);
+                        vl[1] = ((pv[i][2] >> 16) & 0xfffeu) | (pv[i][3] & 0xfffe0000u);
+                        *reinterpret_cast<u32x2 *>(Ph + row * ROWB + k * 2) = vh;
+                        *reinterpret_cast<u32x2 *>(Pl + row * ROWB + k * 2) = vl;
                     }
+                ++sweeps;
+                if (a.dbg && sweeps == 1) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); ph[1] += (long long)__builtin_readcyclecounter() - tst; }
                 if (__all(need == 0)) break;
-                if ((++sweeps & 63) == 0) {
+                if ((sweeps & 63) == 0) {
                     int bad = 0;
                     if (lane == 0) bad = (__hip_atomic_load(abortf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) || (wall_clock64() - t0 > 200000000ll);
                     if (__any(bad)) {
@@ -585,29 +653,60 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_granule_kernel(PersistArgs 
             }
             __syncthreads();
             PSTAMP(0);
+            if (a.dbg) ph[5] += sweeps;
             if (s_fail) return;
+            // gate pre-activations: this step's were requested a whole step ago (right here); request the next step's now,
+            // behind the sweep in the wave's in-order memory queue and with a full step to land
 #pragma unroll
-            for (int ks = 0; ks < KS; ks++) {
+            for (int rt = 0; rt < RTW; rt++)
+#pragma unroll
+                for (int bt = 0; bt < NBT; bt++) g4[rt][bt] = g4n[rt][bt];
+            if (s + 1 < T) load_gx(g4n, d ? (T - 2 - s) : (s + 1));
+            // h fragments: PD reads ahead of the MFMAs that use them (a lone wave per SIMD hides no LDS latency otherwise)
+            constexpr int PD = NBT == 1 ? 3 : 1;
+            bf16x8 qh[PD][NBT], ql[PD][NBT];
+#pragma unroll
+            for (int p = 0; p < PD; p++)
 #pragma unroll
                 for (int bt = 0; bt < NBT; bt++) {
-                    const bf16x8 bh = *reinterpret_cast<const bf16x8 *>(Ph + (bt * 16 + li) * ROWB + ks * 64 + kq * 16);
-                    const bf16x8 bl = *reinterpret_cast<const bf16x8 *>(Pl + (bt * 16 + li) * ROWB + ks * 64 + kq * 16);
+                    qh[p][bt] = *reinterpret_cast<const bf16x8 *>(Ph + (bt * 16 + li) * ROWB + p * 64 + kq * 16);
+                    ql[p][bt] = *reinterpret_cast<const bf16x8 *>(Pl + (bt * 16 + li) * ROWB + p * 64 + kq * 16);
+                }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int ks = 0; ks < KS; ks++) {
+                bf16x8 ch[NBT], cl[NBT];
+#pragma unroll
+                for (int bt = 0; bt < NBT; bt++) { ch[bt] = qh[ks % PD][bt]; cl[bt] = ql[ks % PD][bt]; }
+                if (ks + PD < KS) {
+#pragma unroll
+                    for (int bt = 0; bt < NBT; bt++) {
+                        qh[ks % PD][bt] = *reinterpret_cast<const bf16x8 *>(Ph + (bt * 16 + li) * ROWB + (ks + PD) * 64 + kq * 16);
+                        ql[ks % PD][bt] = *reinterpret_cast<const bf16x8 *>(Pl + (bt * 16 + li) * ROWB + (ks + PD) * 64 + kq * 16);
+                    }
+                }
+#pragma unroll
+                for (int bt = 0; bt < NBT; bt++) {
+                    const bf16x8 bh = ch[bt], bl = cl[bt];
                     // product-major order: consecutive MFMAs hit different accumulators (no dependent-issue stall);
                     // each accumulator still sees ah.bl, al.bh, ah.bh in that order (bit-identical to the step kernel)
+                    // (the scheduler would otherwise regroup them per accumulator into dependent back-to-back pairs)
 #pragma unroll
                     for (int rt = 0; rt < RTW; rt++) acc[rt][bt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[rt][ks], bl, acc[rt][bt], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int rt = 0; rt < RTW; rt++) acc[rt][bt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[rt][ks], bh, acc[rt][bt], 0, 0, 0);
+                    for (int rt = 0; rt < RTW; rt++) mfma_a(acc[rt][bt], al[rt][ks], bh);   // lo fragments stay in AGPRs and feed the MFMA from there
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int rt = 0; rt < RTW; rt++) acc[rt][bt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[rt][ks], bh, acc[rt][bt], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
             __syncthreads();   // every wave is done with the LDS panel before the next step's sweep overwrites it
         }
         PSTAMP(2);
         // ---- cell update; publish h_s as tagged granules (no drain, no signal)
-        u64 *dst = hxg + (size_t)((s & 1) * 32 + team) * pgran;
-        float hcur[RTW][NBT];
+        const unsigned tg = (unsigned)(s % 3 + 1), t0b = (tg & 1u) << 16, t1b = (tg >> 1) << 16;
 #pragma unroll
         for (int rt = 0; rt < RTW; rt++)
 #pragma unroll
@@ -619,32 +718,34 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_granule_kernel(PersistArgs 
                 const float cn = fg * cst[rt][bt] + ig * cg;
                 const float hn = valid ? og * fast_tanh(cn) : 0.f;
                 cst[rt][bt] = cn;
-                hcur[rt][bt] = hn;
-                __bf16 hb = (__bf16)hn, lbf = (__bf16)(hn - (float)hb);
-                const unsigned int data = (unsigned int)*reinterpret_cast<unsigned short *>(&hb) | ((unsigned int)*reinterpret_cast<unsigned short *>(&lbf) << 16);
-                if (s + 1 < T) st_agent(dst + (size_t)lb * H + unit[rt], (u64)(unsigned)(s + 1) | ((u64)data << 32));
+                {
+                    const int ul = (wave * RTW + rt) * 4 + kq;
+                    const float ov = hn * osc[rt] + osh[rt];
+                    __bf16 ob = (__bf16)ov, ol = (__bf16)(ov - (float)ob);
+                    Oh[lb * UW + ul] = *reinterpret_cast<unsigned short *>(&ob);
+                    Ol[lb * UW + ul] = *reinterpret_cast<unsigned short *>(&ol);
+                    Of[lb * UW + ul] = hn;
+                }
+                Og[lb * UW + (wave * RTW + rt) * 4 + kq] = split_h(hn) | ((kq & 1) ? t1b : t0b);   // even unit: tag bit 0, odd unit: bit 1
             }
         PSTAMP(3);
-#pragma unroll
-        for (int rt = 0; rt < RTW; rt++)
-#pragma unroll
-            for (int bt = 0; bt < NBT; bt++) {
-                const int lb = bt * 16 + li, b = g * a.BGr + lb;
-                if (lb < a.BGr && b < B) {
-                    const float hn = hcur[rt][bt];
-                    const size_t oi = ((size_t)t * B + b) * 2 * H + d * H + unit[rt];
-                    if (a.out_raw) a.out_raw[oi] = hn;
-                    const float ov = hn * osc[rt] + osh[rt];
-                    if (a.out && a.out != a.out_raw) a.out[oi] = ov;
-                    if (a.out_split.hi) {
-                        __bf16 ob = (__bf16)ov, ol = (__bf16)(ov - (float)ob);
-                        a.out_split.hi[oi] = *reinterpret_cast<unsigned short *>(&ob);
-                        a.out_split.lo[oi] = *reinterpret_cast<unsigned short *>(&ol);
-                    }
-                }
+        __syncthreads();                                             // the tiles are complete
+        // ---- publish h_s (no drain, no signal): the workgroup's slice of every row is one 4*UW-byte run of whole 64-byte
+        // lines, written as 16-byte write-through stores (a lane-per-unit store is 16 partial lines per instruction, and
+        // the sweep that follows in the same in-order queue waits for every one of those acknowledgements)
+        if (s + 1 < T) {
+            const __amdgpu_buffer_rsrc_t drs = __builtin_amdgcn_make_buffer_rsrc(hxg + (size_t)((s & 1) * 32 + team) * pgran, 0, (int)(pgran * 8), 0x00020000);
+            constexpr int CG = UW / 4;                                 // 16-byte chunks per row
+            for (int q = tid; q < BGC * CG; q += NTH) {
+                const int lb = q / CG, c = q - lb * CG;
+                if (lb < a.BGr)
+                    __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4 *>(Og + lb * UW + c * 4), drs,
+                                                           (lb * (H / 2) + member * (UW / 2)) * 8 + c * 16, 0, 16 /* sc1 */);
             }
+        }
         PSTAMP(4);
     }
+    store_out(d ? 0 : (T - 1));                                     // the last step's outputs (the others leave during the next sweep)
     if (a.dbg && tid == 0) for (int i = 0; i < 6; i++) a.dbg[blockIdx.x * 6 + i] = ph[i];
 }
 
@@ -653,9 +754,9 @@ int granule_bg(int B) { const int r = (B + 15) / 16; return r <= 16 ? 16 : 32; }
 template <int H, int NBT, int RTW>
 static int launch_granule_t(PersistArgs a, hipStream_t st) {
     constexpr int ROWB = H * 2 + 16;
-    const size_t smem = (size_t)2 * NBT * 16 * ROWB;
+    const size_t smem = (size_t)2 * NBT * 16 * ROWB + (size_t)NBT * 16 * (H / 8) * 12;   // h panels + tiles (2 bf16 planes + fp32 + tagged h words)
     MDD_HIP_CHECK(hipMemsetAsync(a.sync, 0, 32 * sizeof(unsigned int), st));
-    MDD_HIP_CHECK(hipMemsetAsync(a.hx, 0, (size_t)2 * 32 * NBT * 16 * H * 8, st));   // tags must start at 0 on every launch
+    MDD_HIP_CHECK(hipMemsetAsync(a.hx, 0, (size_t)2 * 32 * NBT * 16 * H * 4, st));   // tags must start at 0 on every launch
     hipLaunchKernelGGL((lstm_layer_granule_kernel<H, NBT, RTW>), dim3(256), dim3(256), smem, st, a);
     MDD_LAUNCH_CHECK();
     return MDD_OK;
@@ -667,7 +768,9 @@ int launch_lstm_layer_granule(const LstmStepArgs &s, unsigned short *hx, unsigne
     a.out = s.out; a.out_raw = s.out_raw; a.out_split = s.out_split; a.oscale = s.oscale; a.oshift = s.oshift;
     a.T = s.T; a.B = s.B; a.BGr = (s.B + 15) / 16; a.BG = granule_bg(s.B);
     a.dbg = (getenv("MDD_LSTM_DBG") && s.T > 100) ? reinterpret_cast<long long *>(reinterpret_cast<u64 *>(hx) + (size_t)2 * 32 * a.BG * s.H) : nullptr;
+    a.exp = getenv("MDD_LSTM_EXP") ? atoi(getenv("MDD_LSTM_EXP")) : 0;
     if (a.oscale == nullptr) a.oshift = nullptr;
+    if (a.out && a.out != a.out_raw) { set_error("granule lstm: a separate scaled fp32 output is not supported (split planes carry it)"); return MDD_ERR_ARG; }
     const int nbt = a.BG / 16;
     if (s.H == 384) return nbt == 1 ? launch_granule_t<384, 1, 3>(a, st) : launch_granule_t<384, 2, 3>(a, st);
     if (s.H == 256) return nbt == 1 ? launch_granule_t<256, 1, 2>(a, st) : launch_granule_t<256, 2, 2>(a, st);

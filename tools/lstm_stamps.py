@@ -15,9 +15,9 @@ for B in [int(v) for v in (sys.argv[1:] or ['64', '256'])]:
     for _ in range(2): m.forward(x, x1)
     torch.cuda.synchronize()
     ph = m.tap('lstm_dbg').view(torch.int64).view(256, 6).cpu().numpy().astype(np.float64)
-    names = ['wait team', 'panel load+LDS', 'MFMA', 'cell+publish', 'drain+barrier+arrive', '-']
-    tot = ph[:, :5].sum(1)
+    names = ['wait team', '(of which: until 1st pass landed)', 'MFMA', 'cell+publish', 'output stores', '-']
+    tot = ph[:, [0, 2, 3, 4]].sum(1)
     print('B=%d  cycles per step (mean over WGs / max WG):' % B)
     for i in range(5):
-        print('  %-22s %8.0f  (%4.1f%%)   max %8.0f' % (names[i], ph[:, i].mean() / 250, 100 * ph[:, i].mean() / tot.mean(), ph[:, i].max() / 250))
-    print('  total %8.0f cycles/step' % (tot.mean() / 250))
+        print('  %-34s %8.0f  (%4.1f%%)   max %8.0f' % (names[i], ph[:, i].mean() / 250, 100 * ph[:, i].mean() / tot.mean(), ph[:, i].max() / 250))
+    print('  total %8.0f cycles/step; sweep passes per step: mean %.2f max %.2f' % (tot.mean() / 250, ph[:, 5].mean() / 249, ph[:, 5].max() / 249))
