@@ -126,22 +126,34 @@ __global__ __launch_bounds__(256) void attn_tail_kernel(const float *__restrict_
 //   logits[16x48] = y[16 x 4H] . Wfc^T             : K split over the 4 waves, partials summed through LDS
 // Wfc is repacked at weight-load time into the order the lanes consume it (zero rows for n >= C):
 //   wfcp[w][nt][j][lane][m] = Wfc[nt*16 + (lane&15)][w*(4H/4) + 16 j + 4 (lane>>4) + m]
-// dynamic LDS: attw[16][Lp] | y[16][D2 + 4] | part[4][16][48]
+// The x half of y = BN(X) never touches LDS: waves 0 and 1 (whose K quarters lie in it) read their A operands
+// straight from X, 16 bytes per lane.  Only the context half is staged, so a workgroup holds ~65 KB and two fit a
+// CU (the kernel is a chain of global-load latencies: a second resident workgroup is what hides them).  In the
+// context product the V values of the next column tile are requested before the current tile's MFMAs.
+// dynamic LDS: attw[16][LA] | yc[16][H2 + 4] | part[4][16][48]
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-__global__ __launch_bounds__(256) void attn_tail_mfma_kernel(const float *__restrict__ S, int Lp, const float *__restrict__ X,
+__global__ __launch_bounds__(256, 2) void attn_tail_mfma_kernel(const float *__restrict__ S, int Lp, const float *__restrict__ X,
                                                              const float *__restrict__ V, const float *__restrict__ fscale,
                                                              const float *__restrict__ fshift, const float *__restrict__ wfcp,
                                                              float *__restrict__ logp, int Tp, int B, int L, int H2, int C) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int D2 = 2 * H2, LDY = D2 + 4, LA = (L + 3) & ~3;
+    const int D2 = 2 * H2, LDY = H2 + 4, LA = (L + 3) & ~3;
     float *attw = smem;                  // [16][LA]
-    float *y = attw + 16 * LA;           // [16][LDY]
-    float *part = y + 16 * LDY;          // [4][16][48]
+    float *yc = attw + 16 * LA;          // [16][LDY]   context half of y
+    float *part = yc + 16 * LDY;         // [4][16][48]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, kq = lane >> 4;
     const int b = blockIdx.y, t0 = blockIdx.x * 16;
     const int nt_rows = min(16, Tp - t0);
+
+    // classifier operand addresses
+    const int J = D2 / 64;               // float4 groups per wave quarter (J % 4 == 0: D2 % 256 == 0 for H in {256, 384})
+    const float4 *wp = reinterpret_cast<const float4 *>(wfcp) + (size_t)wave * 3 * J * 64 + lane;
+    const bool xhalf = wave < 2;         // this wave's K quarter [wave*D2/4, +D2/4) lies in the x half (H2 = 2 quarters)
+    const int xrow = min(t0 + li, Tp - 1);
+    const float *xsrc = X + ((size_t)xrow * B + b) * H2 + wave * (D2 / 4) + 4 * kq;   // + 16 j
+    const float *scp = fscale + wave * (D2 / 4) + 4 * kq, *shp = fshift + wave * (D2 / 4) + 4 * kq;
 
     // 1. softmax over L (one wave per row); padded rows / columns are zero
     for (int r = wave; r < 16; r += 4) {
@@ -156,49 +168,82 @@ __global__ __launch_bounds__(256) void attn_tail_mfma_kernel(const float *__rest
         for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
         for (int l = lane; l < L; l += 64) arow[l] = arow[l] / sum;
     }
-    // x half of y = BN(X)
-    for (int i = tid; i < 16 * H2; i += 256) {
-        const int r = i / H2, d = i - r * H2;
-        const float xv = r < nt_rows ? X[((size_t)(t0 + r) * B + b) * H2 + d] : 0.f;
-        y[r * LDY + d] = xv * fscale[d] + fshift[d];
-    }
     __syncthreads();
 
     // 2. ctx tiles: A = attw[row li][k], B = V[k = l][col d].  All V values of a tile are requested before the first MFMA
-    //    (a lone dependent global load per k-step cost ~500 cycles each: 120 of them per wave dominated this kernel).
-    for (int nt = wave; nt * 16 < H2; nt += 4) {
-        const int d = nt * 16 + li;
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        for (int k0 = 0; k0 < LA; k0 += 64) {
-            float vv[16];
+    //    (a lone dependent global load per k-step cost ~500 cycles each), and one tile ahead of the MFMAs.
+    {
+        auto loadV = [&](float (&vv)[16], int nt, int k0) {
+            const int d = nt * 16 + li;
 #pragma unroll
             for (int i = 0; i < 16; i++) {
                 const int l = k0 + 4 * i + kq;
-                vv[i] = (k0 + 4 * i < LA) ? V[((size_t)(l < L ? l : L - 1) * B + b) * H2 + d] : 0.f;   // attw is 0 for l >= L
+                vv[i] = (k0 + 4 * i < LA && nt * 16 < H2) ? V[((size_t)(l < L ? l : L - 1) * B + b) * H2 + (d < H2 ? d : 0)] : 0.f;   // attw is 0 for l >= L
             }
+        };
+        if (LA <= 64) {   // the usual case (L <= 64): one k block per tile, software-pipelined over the tiles
+            float va[16], vb[16];
+            loadV(va, wave, 0);
+            for (int nt = wave; nt * 16 < H2; nt += 8) {
+                loadV(vb, nt + 4, 0);
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int i = 0; i < 16; i++)
-                if (k0 + 4 * i < LA) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(attw[li * LA + k0 + 4 * i + kq], vv[i], acc, 0, 0, 0);
+                for (int i = 0; i < 16; i++)
+                    if (4 * i < LA) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(attw[li * LA + 4 * i + kq], va[i], acc, 0, 0, 0);
+                {
+                    const int d = nt * 16 + li;
+                    const float sc = fscale[H2 + d], hc = fshift[H2 + d];
+#pragma unroll
+                    for (int r = 0; r < 4; r++) yc[(kq * 4 + r) * LDY + d] = acc[r] * sc + hc;   // D: row = 4*(lane>>4)+r, col = lane&15
+                }
+                if ((nt + 4) * 16 < H2) {
+                    loadV(va, nt + 8, 0);
+                    f32x4 acc2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int i = 0; i < 16; i++)
+                        if (4 * i < LA) acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(attw[li * LA + 4 * i + kq], vb[i], acc2, 0, 0, 0);
+                    const int d = (nt + 4) * 16 + li;
+                    const float sc = fscale[H2 + d], hc = fshift[H2 + d];
+#pragma unroll
+                    for (int r = 0; r < 4; r++) yc[(kq * 4 + r) * LDY + d] = acc2[r] * sc + hc;
+                }
+            }
+        } else {
+            for (int nt = wave; nt * 16 < H2; nt += 4) {
+                const int d = nt * 16 + li;
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                for (int k0 = 0; k0 < LA; k0 += 64) {
+                    float vv[16];
+                    loadV(vv, nt, k0);
+#pragma unroll
+                    for (int i = 0; i < 16; i++)
+                        if (k0 + 4 * i < LA) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(attw[li * LA + k0 + 4 * i + kq], vv[i], acc, 0, 0, 0);
+                }
+                const float sc = fscale[H2 + d], hc = fshift[H2 + d];
+#pragma unroll
+                for (int r = 0; r < 4; r++) yc[(kq * 4 + r) * LDY + d] = acc[r] * sc + hc;
+            }
         }
-        const float sc = fscale[H2 + d], hc = fshift[H2 + d];
-#pragma unroll
-        for (int r = 0; r < 4; r++) y[(kq * 4 + r) * LDY + H2 + d] = acc[r] * sc + hc;   // D: row = 4*(lane>>4)+r, col = lane&15
     }
     __syncthreads();
 
     // 3. classifier: this wave's quarter of K, three 16-column tiles
     {
-        const int J = D2 / 64;   // float4 groups per wave quarter
-        const float4 *wp = reinterpret_cast<const float4 *>(wfcp) + (size_t)wave * 3 * J * 64 + lane;
-        const float *yr = y + li * LDY + wave * (D2 / 4) + 4 * kq;
+        const float *yr = yc + li * LDY + (xhalf ? 0 : wave - 2) * (D2 / 4) + 4 * kq;   // context half (waves 2, 3)
         f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0;
-        for (int j0 = 0; j0 < J; j0 += 4) {      // J % 4 == 0 (D2 % 256 == 0 for H in {256, 384})
+        for (int j0 = 0; j0 < J; j0 += 4) {
             float4 y4[4], w0[4], w1[4], w2[4];
 #pragma unroll
             for (int u = 0; u < 4; u++) {
                 const int j = j0 + u;
-                y4[u] = *reinterpret_cast<const float4 *>(yr + 16 * j);
                 w0[u] = wp[(0 * J + j) * 64]; w1[u] = wp[(1 * J + j) * 64]; w2[u] = wp[(2 * J + j) * 64];
+                if (xhalf) {
+                    const float4 xv = *reinterpret_cast<const float4 *>(xsrc + 16 * j);
+                    const float4 sc = *reinterpret_cast<const float4 *>(scp + 16 * j), sh = *reinterpret_cast<const float4 *>(shp + 16 * j);
+                    y4[u] = make_float4(xv.x * sc.x + sh.x, xv.y * sc.y + sh.y, xv.z * sc.z + sh.z, xv.w * sc.w + sh.w);
+                } else {
+                    y4[u] = *reinterpret_cast<const float4 *>(yr + 16 * j);
+                }
             }
 #pragma unroll
             for (int u = 0; u < 4; u++) {
@@ -243,7 +288,7 @@ int launch_attn_tail(const float *S, int Lp, const float *X, const float *V, con
                      const float *wfc, const float *wfcp, float *logp, int Tp, int B, int L, int H2, int C, hipStream_t st) {
     if (wfcp && (2 * H2) % 256 == 0 && C <= 48) {
         const int D2 = 2 * H2, LA = (L + 3) & ~3;
-        size_t smem = sizeof(float) * ((size_t)16 * LA + (size_t)16 * (D2 + 4) + 4 * 16 * 48);
+        size_t smem = sizeof(float) * ((size_t)16 * LA + (size_t)16 * (H2 + 4) + 4 * 16 * 48);
         if (smem > 160 * 1024) { set_error("attn_tail: L=%d too long for the LDS tile (%zu B)", L, smem); return MDD_ERR_ARG; }
         hipLaunchKernelGGL(attn_tail_mfma_kernel, dim3((Tp + 15) / 16, B), dim3(256), smem, st, S, Lp, X, V, fscale, fshift, wfcp,
                            logp, Tp, B, L, H2, C);
