@@ -35,8 +35,8 @@ PEAK_HBM_GBS = 8000.0
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=128)
+    ap.add_argument("--warmup", type=int, default=16)
     ap.add_argument("--workload", default="joint64", choices=["joint64", "greedy32"])
     ap.add_argument("--hidden", type=int, default=384)
     ap.add_argument("--lanes", type=int, default=1, help="independent stream pipelines per GPU")
@@ -229,7 +229,7 @@ def main():
         from oracle import ref_port
         ncores = min(os.cpu_count() or 1, 16)
         torch.set_num_threads(ncores)
-        sb = 8
+        sb = min(B0, 64)                                              # one reference-sized batch: ~10 s of CPU work
         xs = stack_features(raw[:sb]).cpu().numpy()
         ref_port.forward(sd, xs[:1, :64], x1_np[:1])                       # warm-up
         t1 = time.perf_counter()
