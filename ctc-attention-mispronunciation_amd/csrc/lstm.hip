@@ -320,7 +320,6 @@ struct PersistArgs {
     const float *oscale, *oshift;
     int T, B, BG, BGr;               // BG: padded rows per group (multiple of 16), BGr: real rows per group
     long long *dbg;                  // diagnostic builds only: per-workgroup cycle sums of the step phases (null in production)
-    int exp;                         // MDD_LSTM_EXP: experiment bits (0 in production)
 };
 
 typedef unsigned long long u64;
@@ -768,7 +767,6 @@ int launch_lstm_layer_granule(const LstmStepArgs &s, unsigned short *hx, unsigne
     a.out = s.out; a.out_raw = s.out_raw; a.out_split = s.out_split; a.oscale = s.oscale; a.oshift = s.oshift;
     a.T = s.T; a.B = s.B; a.BGr = (s.B + 15) / 16; a.BG = granule_bg(s.B);
     a.dbg = (getenv("MDD_LSTM_DBG") && s.T > 100) ? reinterpret_cast<long long *>(reinterpret_cast<u64 *>(hx) + (size_t)2 * 32 * a.BG * s.H) : nullptr;
-    a.exp = getenv("MDD_LSTM_EXP") ? atoi(getenv("MDD_LSTM_EXP")) : 0;
     if (a.oscale == nullptr) a.oshift = nullptr;
     if (a.out && a.out != a.out_raw) { set_error("granule lstm: a separate scaled fp32 output is not supported (split planes carry it)"); return MDD_ERR_ARG; }
     const int nbt = a.BG / 16;
