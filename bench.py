@@ -40,7 +40,7 @@ def parse():
     ap.add_argument("--workload", default="joint64", choices=["joint64", "greedy32"])
     ap.add_argument("--hidden", type=int, default=384)
     ap.add_argument("--lanes", type=int, default=1, help="independent stream pipelines per GPU")
-    ap.add_argument("--fuse", type=int, default=4, help="reference-sized batches carried by one launch sequence")
+    ap.add_argument("--fuse", type=int, default=8, help="reference-sized batches carried by one launch sequence")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true", help="skip the posterior all-gather at N>1")
     ap.add_argument("--decoder", default=None, choices=[None, "beam", "greedy", "none"], help="diagnostic override of the decode stage")

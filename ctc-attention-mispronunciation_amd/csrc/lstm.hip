@@ -507,16 +507,20 @@ __device__ __forceinline__ void mfma_a(f32x4 &acc, const bf16x8 &a_agpr, const b
 // differ; the exchange buffer is zeroed before every launch (tag 0 is never valid), so replays cannot see a previous
 // launch's data.  The sweep is bound by the bytes all 256 workgroups pull past their L2s (measured: ~110 cycles per
 // KB of panel), hence the dense format: 4 bytes per unit and row, and only the team's real batch rows.
+// A team's batch rows come in NBT tiles of 16 (one MFMA column tile each).  The tiles are independent recurrences and
+// are advanced ALTERNATELY, each with its own panel and epoch: while tile 0's h_s travels to the team (the hand-off is
+// ~2 us of pure latency), the workgroup runs tile 1's MFMAs and cell update, and vice versa -- with two tiles the
+// matrix cores work through most of what a single tile spends waiting.
 template <int H, int NBT, int RTW>
 __global__ __launch_bounds__(256, 1) void lstm_layer_granule_kernel(PersistArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int NTH = 256, KS = H / 32, ROWB = H * 2 + 16, RM = 4 * H / 8, BGC = NBT * 16;
+    constexpr int NTH = 256, KS = H / 32, ROWB = H * 2 + 16, RM = 4 * H / 8;
     static_assert(RM == 4 * RTW * 16, "4 waves x RTW row tiles must cover the workgroup's gate rows");
-    unsigned char *Ph = smem, *Pl = smem + (size_t)BGC * ROWB;
+    unsigned char *Ph = smem, *Pl = smem + (size_t)16 * ROWB;      // the active tile's h panel, hi / lo planes
     constexpr int UW = RM / 4;                                      // units this workgroup owns (a 2*UW-byte run per output row and plane)
-    unsigned short *Oh = reinterpret_cast<unsigned short *>(smem + (size_t)2 * BGC * ROWB), *Ol = Oh + BGC * UW;   // step outputs, [row][unit]
-    float *Of = reinterpret_cast<float *>(Ol + BGC * UW);
-    unsigned int *Og = reinterpret_cast<unsigned int *>(Of + BGC * UW);   // this step's h as tagged words, [row][unit]
+    unsigned short *Oh = reinterpret_cast<unsigned short *>(smem + (size_t)2 * 16 * ROWB), *Ol = Oh + 16 * UW;   // step outputs, [row][unit]
+    float *Of = reinterpret_cast<float *>(Ol + 16 * UW);
+    unsigned int *Og = reinterpret_cast<unsigned int *>(Of + 16 * UW);   // this step's h as tagged words, [row][unit]
     static_assert(UW % 8 == 0, "output rows must be whole 16-byte chunks");
     __shared__ int s_fail;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -549,202 +553,199 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_granule_kernel(PersistArgs 
     for (int rt = 0; rt < RTW; rt++)
 #pragma unroll
         for (int bt = 0; bt < NBT; bt++) cst[rt][bt] = 0.f;
-    const size_t pgran = (size_t)BGC * H / 2;                      // granules per (parity, team) panel: [row][unit pair]
+    constexpr size_t tgran = (size_t)16 * H / 2;                   // granules per tile panel: [row][unit pair]
+    const size_t pgran = NBT * tgran;                              // granules per (parity, team)
     // rows past the team's real batch rows are never published nor swept: their panel rows stay zero
-    constexpr int NLD0 = BGC * H / 4 / NTH;
-    unsigned need0 = 0;
+    constexpr int NLD = 16 * H / 4 / NTH;                          // 16-byte chunks (2 granules = 4 units) per thread and tile
+    static_assert(16 * H / 4 % NTH == 0 && H % 4 == 0, "panel must be whole passes of the workgroup");
+    unsigned need0[NBT];
 #pragma unroll
-    for (int i = 0; i < NLD0; i++) need0 |= ((4 * (tid + NTH * i)) / H < a.BGr ? 1u : 0u) << i;
-    for (int i = tid; i < 2 * BGC * ROWB / 4; i += NTH) reinterpret_cast<unsigned int *>(smem)[i] = 0u;
+    for (int bt = 0; bt < NBT; bt++) {
+        need0[bt] = 0;
+#pragma unroll
+        for (int i = 0; i < NLD; i++) need0[bt] |= (bt * 16 + (4 * (tid + NTH * i)) / H < a.BGr ? 1u : 0u) << i;
+    }
+    for (int i = tid; i < 2 * 16 * ROWB / 4; i += NTH) reinterpret_cast<unsigned int *>(smem)[i] = 0u;
     u64 *hxg = reinterpret_cast<u64 *>(a.hx);
     unsigned int *abortf = a.sync + 16;
     long long ph[6] = {0, 0, 0, 0, 0, 0}, tst = a.dbg ? (long long)__builtin_readcyclecounter() : 0;
     __syncthreads();
 
     // A step's critical path is sweep-complete -> MFMA -> cell -> publish; whatever else a step must issue (the layer
-    // outputs, the next gate pre-activations) goes between the publish and the next sweep, where the workgroup would
-    // only be waiting for its team anyway (placed after the sweep they cost their full issue time on every step).
+    // outputs, the next gate pre-activations) is placed where the workgroup is not on that chain: the outputs of the
+    // previous phase leave right behind the first sweep pass, the gate pre-activations are requested a whole step ahead.
     float4 g4[RTW][NBT], g4n[RTW][NBT];
-    auto load_gx = [&](float4 (&dstg)[RTW][NBT], int tt) {
+    auto load_gx = [&](float4 (&dstg)[RTW][NBT], int bt, int tt) {
 #pragma unroll
-        for (int rt = 0; rt < RTW; rt++)
-#pragma unroll
-            for (int bt = 0; bt < NBT; bt++) {
-                const int lb = bt * 16 + li, b = g * a.BGr + lb;
-                const bool valid = lb < a.BGr && b < B;
-                dstg[rt][bt] = valid ? *reinterpret_cast<const float4 *>(a.gx + (((size_t)tt * B + b) * 2 + d) * 4 * H + unit[rt] * 4)
-                                     : make_float4(0.f, 0.f, 0.f, 0.f);
-            }
+        for (int rt = 0; rt < RTW; rt++) {
+            const int lb = bt * 16 + li, b = g * a.BGr + lb;
+            const bool valid = lb < a.BGr && b < B;
+            const float4 v = valid ? *reinterpret_cast<const float4 *>(a.gx + (((size_t)tt * B + b) * 2 + d) * 4 * H + unit[rt] * 4)
+                                   : make_float4(0.f, 0.f, 0.f, 0.f);
+            if (bt == 0) dstg[rt][0] = v; else dstg[rt][NBT - 1] = v;
+        }
     };
     // Layer outputs leave through an LDS tile: the cell update drops its (row, unit) values there, and after the next
     // barrier the workgroup writes each output row's run as 16-byte chunks (a lane-per-unit store would be 2-byte
     // pieces over 16 rows: ~24 issue-bound store instructions per step instead of 3).
-    auto store_out = [&](int tt) {
+    auto store_out = [&](int bt, int tt) {
         constexpr int CH = UW / 8, CF = UW / 4;                       // 16-byte chunks per row: bf16 planes, fp32
         if (a.out_split.hi) {
-            for (int q = tid; q < 2 * BGC * CH; q += NTH) {
-                const int pl = q >= BGC * CH, qq = pl ? q - BGC * CH : q, lb = qq / CH, c = qq - lb * CH, b = g * a.BGr + lb;
+            for (int q = tid; q < 2 * 16 * CH; q += NTH) {
+                const int pl = q >= 16 * CH, qq = pl ? q - 16 * CH : q, r = qq / CH, c = qq - r * CH, lb = bt * 16 + r, b = g * a.BGr + lb;
                 if (lb < a.BGr && b < B) {
-                    const u32x4 v = *reinterpret_cast<const u32x4 *>((pl ? Ol : Oh) + lb * UW + c * 8);
+                    const u32x4 v = *reinterpret_cast<const u32x4 *>((pl ? Ol : Oh) + r * UW + c * 8);
                     *reinterpret_cast<u32x4 *>((pl ? a.out_split.lo : a.out_split.hi) + ((size_t)tt * B + b) * 2 * H + d * H + member * UW + c * 8) = v;
                 }
             }
         }
         if (a.out_raw) {
-            for (int q = tid; q < BGC * CF; q += NTH) {
-                const int lb = q / CF, c = q - lb * CF, b = g * a.BGr + lb;
+            for (int q = tid; q < 16 * CF; q += NTH) {
+                const int r = q / CF, c = q - r * CF, lb = bt * 16 + r, b = g * a.BGr + lb;
                 if (lb < a.BGr && b < B)
                     *reinterpret_cast<u32x4 *>(a.out_raw + ((size_t)tt * B + b) * 2 * H + d * H + member * UW + c * 4) =
-                        *reinterpret_cast<const u32x4 *>(Of + lb * UW + c * 4);
+                        *reinterpret_cast<const u32x4 *>(Of + r * UW + c * 4);
             }
         }
     };
-    load_gx(g4, d ? (T - 1) : 0);
-    if (T > 1) load_gx(g4n, d ? (T - 2) : 1);
+#pragma unroll
+    for (int bt = 0; bt < NBT; bt++) {
+        load_gx(g4, bt, d ? (T - 1) : 0);
+        if (T > 1) load_gx(g4n, bt, d ? (T - 2) : 1);
+    }
+    int pend_bt = -1, pend_t = 0;                                   // the phase whose outputs still sit in the LDS tiles
     for (int s = 0; s < T; s++) {
         const int t = d ? (T - 1 - s) : s;
-        f32x4 acc[RTW][NBT];
 #pragma unroll
-        for (int rt = 0; rt < RTW; rt++)
+        for (int bt = 0; bt < NBT; bt++) {
+            f32x4 acc[RTW];
 #pragma unroll
-            for (int bt = 0; bt < NBT; bt++) acc[rt][bt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (s > 0) {
-            // ---- sweep this thread's share of the team's panel (parity (s-1)&1) until every tag == s
-            const u64 *srcp = hxg + (size_t)(((s - 1) & 1) * 32 + team) * pgran;
-            const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<u64 *>(srcp), 0, (int)(pgran * 8), 0x00020000);
-            constexpr int NLD = BGC * H / 4 / NTH;                  // 16-byte chunks (2 granules = 4 units) per thread
-            static_assert(BGC * H / 4 % NTH == 0 && H % 4 == 0, "panel must be whole passes of the workgroup");
-            unsigned need = need0;
-            const unsigned ep = (unsigned)((s - 1) % 3 + 1), e0 = (ep & 1u) << 16, e1 = (ep >> 1) << 16;   // tag of step s-1
-            int sweeps = 0;
-            const long long t0 = wall_clock64();
-            bool first = true;
-            while (true) {
-                u32x4 pv[NLD];
+            for (int rt = 0; rt < RTW; rt++) acc[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (s > 0) {
+                // ---- sweep this thread's share of the tile's panel (parity (s-1)&1) until every tag is step s-1's
+                const u64 *srcp = hxg + (size_t)(((s - 1) & 1) * 32 + team) * pgran + bt * tgran;
+                const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<u64 *>(srcp), 0, (int)(tgran * 8), 0x00020000);
+                unsigned need = need0[bt];
+                const unsigned ep = (unsigned)((s - 1) % 3 + 1), e0 = (ep & 1u) << 16, e1 = (ep >> 1) << 16;   // tag of step s-1
+                int sweeps = 0;
+                const long long t0 = wall_clock64();
+                bool first = true;
+                while (true) {
+                    u32x4 pv[NLD];
 #pragma unroll
-                for (int i = 0; i < NLD; i++)
-                    if (need & (1u << i)) pv[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (tid + NTH * i) * 16, 0, 16 /* sc1 */);
-                if (first) { store_out(d ? (T - s) : (s - 1)); first = false; }   // step s-1's outputs, behind the sweep in the queue
+                    for (int i = 0; i < NLD; i++)
+                        if (need & (1u << i)) pv[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (tid + NTH * i) * 16, 0, 16 /* sc1 */);
+                    if (first) { if (pend_bt >= 0) store_out(pend_bt, pend_t); first = false; }   // the previous phase's outputs, behind the sweep in the queue
 #pragma unroll
-                for (int i = 0; i < NLD; i++)
-                    if ((need & (1u << i)) && (pv[i][0] & 0x10000u) == e0 && (pv[i][1] & 0x10000u) == e1 &&
-                        (pv[i][2] & 0x10000u) == e0 && (pv[i][3] & 0x10000u) == e1) {
-                        need &= ~(1u << i);
-                        const int q = tid + NTH * i, row = (4 * q) / H, k = 4 * q - row * H;
-                        u32x2 vh, vl;
-                        vh[0] = (pv[i][0] & 0xffffu) | (pv[i][1] << 16); vh[1] = (pv[i][2] & 0xffffu) | (pv[i][3] << 16);
-                        vl[0] = ((pv[i][0] >> 16) & 0xfffeu) | (pv[i][1] & 0xfffe0000u);
-                        vl[1] = ((pv[i][2] >> 16) & 0xfffeu) | (pv[i][3] & 0xfffe0000u);
-                        *reinterpret_cast<u32x2 *>(Ph + row * ROWB + k * 2) = vh;
-                        *reinterpret_cast<u32x2 *>(Pl + row * ROWB + k * 2) = vl;
-                    }
-                ++sweeps;
-                if (a.dbg && sweeps == 1) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); ph[1] += (long long)__builtin_readcyclecounter() - tst; }
-                if (__all(need == 0)) break;
-                if ((sweeps & 63) == 0) {
-                    int bad = 0;
-                    if (lane == 0) bad = (__hip_atomic_load(abortf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) || (wall_clock64() - t0 > 200000000ll);
-                    if (__any(bad)) {
-                        if (lane == 0) { __hip_atomic_store(abortf, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); atomicExch(a.err_flag, 2); s_fail = 1; }
-                        break;
-                    }
-                }
-            }
-            __syncthreads();
-            PSTAMP(0);
-            if (a.dbg) ph[5] += sweeps;
-            if (s_fail) return;
-            // gate pre-activations: this step's were requested a whole step ago (right here); request the next step's now,
-            // behind the sweep in the wave's in-order memory queue and with a full step to land
-#pragma unroll
-            for (int rt = 0; rt < RTW; rt++)
-#pragma unroll
-                for (int bt = 0; bt < NBT; bt++) g4[rt][bt] = g4n[rt][bt];
-            if (s + 1 < T) load_gx(g4n, d ? (T - 2 - s) : (s + 1));
-            // h fragments: PD reads ahead of the MFMAs that use them (a lone wave per SIMD hides no LDS latency otherwise)
-            constexpr int PD = NBT == 1 ? 3 : 1;
-            bf16x8 qh[PD][NBT], ql[PD][NBT];
-#pragma unroll
-            for (int p = 0; p < PD; p++)
-#pragma unroll
-                for (int bt = 0; bt < NBT; bt++) {
-                    qh[p][bt] = *reinterpret_cast<const bf16x8 *>(Ph + (bt * 16 + li) * ROWB + p * 64 + kq * 16);
-                    ql[p][bt] = *reinterpret_cast<const bf16x8 *>(Pl + (bt * 16 + li) * ROWB + p * 64 + kq * 16);
-                }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int ks = 0; ks < KS; ks++) {
-                bf16x8 ch[NBT], cl[NBT];
-#pragma unroll
-                for (int bt = 0; bt < NBT; bt++) { ch[bt] = qh[ks % PD][bt]; cl[bt] = ql[ks % PD][bt]; }
-                if (ks + PD < KS) {
-#pragma unroll
-                    for (int bt = 0; bt < NBT; bt++) {
-                        qh[ks % PD][bt] = *reinterpret_cast<const bf16x8 *>(Ph + (bt * 16 + li) * ROWB + (ks + PD) * 64 + kq * 16);
-                        ql[ks % PD][bt] = *reinterpret_cast<const bf16x8 *>(Pl + (bt * 16 + li) * ROWB + (ks + PD) * 64 + kq * 16);
+                    for (int i = 0; i < NLD; i++)
+                        if ((need & (1u << i)) && (pv[i][0] & 0x10000u) == e0 && (pv[i][1] & 0x10000u) == e1 &&
+                            (pv[i][2] & 0x10000u) == e0 && (pv[i][3] & 0x10000u) == e1) {
+                            need &= ~(1u << i);
+                            const int q = tid + NTH * i, row = (4 * q) / H, k = 4 * q - row * H;
+                            u32x2 vh, vl;
+                            vh[0] = (pv[i][0] & 0xffffu) | (pv[i][1] << 16); vh[1] = (pv[i][2] & 0xffffu) | (pv[i][3] << 16);
+                            vl[0] = ((pv[i][0] >> 16) & 0xfffeu) | (pv[i][1] & 0xfffe0000u);
+                            vl[1] = ((pv[i][2] >> 16) & 0xfffeu) | (pv[i][3] & 0xfffe0000u);
+                            *reinterpret_cast<u32x2 *>(Ph + row * ROWB + k * 2) = vh;
+                            *reinterpret_cast<u32x2 *>(Pl + row * ROWB + k * 2) = vl;
+                        }
+                    ++sweeps;
+                    if (a.dbg && sweeps == 1) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); ph[1] += (long long)__builtin_readcyclecounter() - tst; }
+                    if (__all(need == 0)) break;
+                    if ((sweeps & 63) == 0) {
+                        int bad = 0;
+                        if (lane == 0) bad = (__hip_atomic_load(abortf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) || (wall_clock64() - t0 > 200000000ll);
+                        if (__any(bad)) {
+                            if (lane == 0) { __hip_atomic_store(abortf, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); atomicExch(a.err_flag, 2); s_fail = 1; }
+                            break;
+                        }
                     }
                 }
+                __syncthreads();
+                PSTAMP(0);
+                if (a.dbg) ph[5] += sweeps;
+                if (s_fail) return;
+                // gate pre-activations: this step's were requested a whole step ago (right here); request the next step's
+                // now, behind the sweep in the wave's in-order memory queue and with a full step to land
 #pragma unroll
-                for (int bt = 0; bt < NBT; bt++) {
-                    const bf16x8 bh = ch[bt], bl = cl[bt];
+                for (int rt = 0; rt < RTW; rt++) g4[rt][bt] = g4n[rt][bt];
+                if (s + 1 < T) load_gx(g4n, bt, d ? (T - 2 - s) : (s + 1));
+                // h fragments: PD reads ahead of the MFMAs that use them (a lone wave per SIMD hides no LDS latency otherwise)
+                constexpr int PD = 3;
+                bf16x8 qh[PD], ql[PD];
+#pragma unroll
+                for (int p = 0; p < PD; p++) {
+                    qh[p] = *reinterpret_cast<const bf16x8 *>(Ph + li * ROWB + p * 64 + kq * 16);
+                    ql[p] = *reinterpret_cast<const bf16x8 *>(Pl + li * ROWB + p * 64 + kq * 16);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int ks = 0; ks < KS; ks++) {
+                    const bf16x8 bh = qh[ks % PD], bl = ql[ks % PD];
+                    if (ks + PD < KS) {
+                        qh[ks % PD] = *reinterpret_cast<const bf16x8 *>(Ph + li * ROWB + (ks + PD) * 64 + kq * 16);
+                        ql[ks % PD] = *reinterpret_cast<const bf16x8 *>(Pl + li * ROWB + (ks + PD) * 64 + kq * 16);
+                    }
                     // product-major order: consecutive MFMAs hit different accumulators (no dependent-issue stall);
                     // each accumulator still sees ah.bl, al.bh, ah.bh in that order (bit-identical to the step kernel)
                     // (the scheduler would otherwise regroup them per accumulator into dependent back-to-back pairs)
 #pragma unroll
-                    for (int rt = 0; rt < RTW; rt++) acc[rt][bt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[rt][ks], bl, acc[rt][bt], 0, 0, 0);
+                    for (int rt = 0; rt < RTW; rt++) acc[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[rt][ks], bl, acc[rt], 0, 0, 0);
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int rt = 0; rt < RTW; rt++) mfma_a(acc[rt][bt], al[rt][ks], bh);   // lo fragments stay in AGPRs and feed the MFMA from there
+                    for (int rt = 0; rt < RTW; rt++) mfma_a(acc[rt], al[rt][ks], bh);   // lo fragments stay in AGPRs and feed the MFMA from there
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int rt = 0; rt < RTW; rt++) acc[rt][bt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[rt][ks], bh, acc[rt][bt], 0, 0, 0);
+                    for (int rt = 0; rt < RTW; rt++) acc[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[rt][ks], bh, acc[rt], 0, 0, 0);
                     __builtin_amdgcn_sched_barrier(0);
                 }
+                __syncthreads();   // every wave is done with the LDS panel before the next sweep overwrites it
             }
-            __syncthreads();   // every wave is done with the LDS panel before the next step's sweep overwrites it
-        }
-        PSTAMP(2);
-        // ---- cell update; publish h_s as tagged granules (no drain, no signal)
-        const unsigned tg = (unsigned)(s % 3 + 1), t0b = (tg & 1u) << 16, t1b = (tg >> 1) << 16;
+            PSTAMP(2);
+            // ---- cell update; h_s goes to the LDS tiles (outputs, and tagged words for the team)
+            const unsigned tg = (unsigned)(s % 3 + 1), t0b = (tg & 1u) << 16, t1b = (tg >> 1) << 16;
 #pragma unroll
-        for (int rt = 0; rt < RTW; rt++)
-#pragma unroll
-            for (int bt = 0; bt < NBT; bt++) {
+            for (int rt = 0; rt < RTW; rt++) {
                 const int lb = bt * 16 + li, b = g * a.BGr + lb;
                 const bool valid = lb < a.BGr && b < B;
-                const float ig = fast_sigmoid(acc[rt][bt][0] + g4[rt][bt].x), fg = fast_sigmoid(acc[rt][bt][1] + g4[rt][bt].y);
-                const float cg = fast_tanh(acc[rt][bt][2] + g4[rt][bt].z), og = fast_sigmoid(acc[rt][bt][3] + g4[rt][bt].w);
+                const float ig = fast_sigmoid(acc[rt][0] + g4[rt][bt].x), fg = fast_sigmoid(acc[rt][1] + g4[rt][bt].y);
+                const float cg = fast_tanh(acc[rt][2] + g4[rt][bt].z), og = fast_sigmoid(acc[rt][3] + g4[rt][bt].w);
                 const float cn = fg * cst[rt][bt] + ig * cg;
                 const float hn = valid ? og * fast_tanh(cn) : 0.f;
                 cst[rt][bt] = cn;
-                {
-                    const int ul = (wave * RTW + rt) * 4 + kq;
-                    const float ov = hn * osc[rt] + osh[rt];
-                    __bf16 ob = (__bf16)ov, ol = (__bf16)(ov - (float)ob);
-                    Oh[lb * UW + ul] = *reinterpret_cast<unsigned short *>(&ob);
-                    Ol[lb * UW + ul] = *reinterpret_cast<unsigned short *>(&ol);
-                    Of[lb * UW + ul] = hn;
+                const int ul = (wave * RTW + rt) * 4 + kq;
+                const float ov = hn * osc[rt] + osh[rt];
+                __bf16 ob = (__bf16)ov, ol = (__bf16)(ov - (float)ob);
+                Oh[li * UW + ul] = *reinterpret_cast<unsigned short *>(&ob);
+                Ol[li * UW + ul] = *reinterpret_cast<unsigned short *>(&ol);
+                Of[li * UW + ul] = hn;
+                Og[li * UW + ul] = split_h(hn) | ((kq & 1) ? t1b : t0b);   // even unit: tag bit 0, odd unit: bit 1
+            }
+            pend_bt = bt; pend_t = t;
+            PSTAMP(3);
+            __syncthreads();                                         // the tiles are complete
+            // ---- publish h_s (no drain, no signal): the workgroup's slice of every row is one 4*UW-byte run of whole
+            // 64-byte lines, written as 16-byte write-through stores (a lane-per-unit store is 16 partial lines per
+            // instruction, and the sweep that follows in the same in-order queue waits for every acknowledgement)
+            if (s + 1 < T) {
+                const __amdgpu_buffer_rsrc_t drs = __builtin_amdgcn_make_buffer_rsrc(hxg + (size_t)((s & 1) * 32 + team) * pgran + bt * tgran, 0, (int)(tgran * 8), 0x00020000);
+                constexpr int CG = UW / 4;                             // 16-byte chunks per row
+                for (int q = tid; q < 16 * CG; q += NTH) {
+                    const int r = q / CG, c = q - r * CG;
+                    if (bt * 16 + r < a.BGr)
+                        __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4 *>(Og + r * UW + c * 4), drs,
+                                                               (r * (H / 2) + member * (UW / 2)) * 8 + c * 16, 0, 16 /* sc1 */);
                 }
-                Og[lb * UW + (wave * RTW + rt) * 4 + kq] = split_h(hn) | ((kq & 1) ? t1b : t0b);   // even unit: tag bit 0, odd unit: bit 1
             }
-        PSTAMP(3);
-        __syncthreads();                                             // the tiles are complete
-        // ---- publish h_s (no drain, no signal): the workgroup's slice of every row is one 4*UW-byte run of whole 64-byte
-        // lines, written as 16-byte write-through stores (a lane-per-unit store is 16 partial lines per instruction, and
-        // the sweep that follows in the same in-order queue waits for every one of those acknowledgements)
-        if (s + 1 < T) {
-            const __amdgpu_buffer_rsrc_t drs = __builtin_amdgcn_make_buffer_rsrc(hxg + (size_t)((s & 1) * 32 + team) * pgran, 0, (int)(pgran * 8), 0x00020000);
-            constexpr int CG = UW / 4;                                 // 16-byte chunks per row
-            for (int q = tid; q < BGC * CG; q += NTH) {
-                const int lb = q / CG, c = q - lb * CG;
-                if (lb < a.BGr)
-                    __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4 *>(Og + lb * UW + c * 4), drs,
-                                                           (lb * (H / 2) + member * (UW / 2)) * 8 + c * 16, 0, 16 /* sc1 */);
+            if (s == 0) {   // no sweep follows for the other tiles' first step: flush the tiles now
+                store_out(bt, t);
+                pend_bt = -1;
+                __syncthreads();
             }
+            PSTAMP(4);
         }
-        PSTAMP(4);
     }
-    store_out(d ? 0 : (T - 1));                                     // the last step's outputs (the others leave during the next sweep)
+    if (pend_bt >= 0) store_out(pend_bt, pend_t);                   // the last phase's outputs (the others left during the next sweep)
     if (a.dbg && tid == 0) for (int i = 0; i < 6; i++) a.dbg[blockIdx.x * 6 + i] = ph[i];
 }
 
@@ -753,7 +754,7 @@ int granule_bg(int B) { const int r = (B + 15) / 16; return r <= 16 ? 16 : 32; }
 template <int H, int NBT, int RTW>
 static int launch_granule_t(PersistArgs a, hipStream_t st) {
     constexpr int ROWB = H * 2 + 16;
-    const size_t smem = (size_t)2 * NBT * 16 * ROWB + (size_t)NBT * 16 * (H / 8) * 12;   // h panels + tiles (2 bf16 planes + fp32 + tagged h words)
+    const size_t smem = (size_t)2 * 16 * ROWB + (size_t)16 * (H / 8) * 12;   // one tile's h panel + tiles (2 bf16 planes + fp32 + tagged h words)
     MDD_HIP_CHECK(hipMemsetAsync(a.sync, 0, 32 * sizeof(unsigned int), st));
     MDD_HIP_CHECK(hipMemsetAsync(a.hx, 0, (size_t)2 * 32 * NBT * 16 * H * 4, st));   // tags must start at 0 on every launch
     hipLaunchKernelGGL((lstm_layer_granule_kernel<H, NBT, RTW>), dim3(256), dim3(256), smem, st, a);
