@@ -58,14 +58,14 @@ struct mdd_model {
     int W1() const { return (cfg.feat + 2 - 3) / 2 + 1; }
     int W2() const { return (W1() + 2 - 3) / 2 + 1; }
     int rnn_in() const { return cfg.channels * W2(); }
-    int granule_max_b = 512;    // MDD_GRANULE_MAXB
+    int granule_max_b = 1024;   // MDD_GRANULE_MAXB
     bool lstm_granule = true;   // persistent kernel with the data-tagged hand-off (MDD_LSTM=counter selects the counter form)
-    bool lstm_persist = true;   // one persistent team-synchronised launch per BiLSTM layer (split-bf16 mode, >= 256 CUs, B <= 512)
+    bool lstm_persist = true;   // one persistent team-synchronised launch per BiLSTM layer (split-bf16 mode, >= 256 CUs, B <= 1024)
     int n_cu = 0;
     unsigned int *sync_words = nullptr;
     bool lstm_x3 = false;   // MDD_LSTM=x3: LDS-tiled split-bf16 step kernel (measured slower than the packed fp32 step; kept for study)
     bool conv_fused() const { return x3() && cfg.feat == 243 && cfg.channels == 32; }
-    bool persist(int B) const { return x3() && lstm_persist && !lstm_x3 && n_cu >= 256 && B <= 512; }
+    bool persist(int B) const { return x3() && lstm_persist && !lstm_x3 && n_cu >= 256 && B <= (lstm_granule ? granule_max_b : 512); }
     bool x3() const {   // the bf16x3 GEMM needs K % 32 == 0 for every contraction and the packed LSTM layouts
         return precision == 1 && (cfg.hidden == 384 || cfg.hidden == 256) && rnn_in() % 32 == 0 && cfg.emb_dim % 32 == 0;
     }

@@ -508,20 +508,37 @@ __device__ __forceinline__ void mfma_a(f32x4 &acc, const bf16x8 &a_agpr, const b
 // launch's data.  The sweep is bound by the bytes all 256 workgroups pull past their L2s (measured: ~110 cycles per
 // KB of panel), hence the dense format: 4 bytes per unit and row, and only the team's real batch rows.
 // A team's batch rows come in NBT tiles of 16 (one MFMA column tile each).  The tiles are independent recurrences and
-// are advanced ALTERNATELY, each with its own panel and epoch: while tile 0's h_s travels to the team (the hand-off is
-// ~2 us of pure latency), the workgroup runs tile 1's MFMAs and cell update, and vice versa -- with two tiles the
-// matrix cores work through most of what a single tile spends waiting.
+// are advanced in turn, each with its own panel and epoch: while one tile's h_s travels to the team (the hand-off is
+// ~2 us of pure latency), the workgroup runs the other tiles' MFMAs and cell updates.  With three or more tiles a
+// tile's panel has been complete for a whole phase when its turn comes, so its sweep is requested one phase AHEAD
+// (into registers, behind nothing in the memory queue) and costs only the tag check; with two tiles it is requested
+// after the MFMAs of the phase before (the panel is not complete earlier); with one there is nothing to overlap.
+// The gate pre-activations never occupy registers: each tile's next [16 rows x 4*UW] slab is fetched by LDS-DMA as
+// soon as the cell update has consumed the current one.
+typedef __attribute__((address_space(3))) void lds_void_t;
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() carries a workgroup-scope release fence, which on
+// gfx950 is s_waitcnt vmcnt(0): every barrier would drain the write-through publish stores, the output stores and the
+// in-flight LDS-DMA / sweep requests this kernel deliberately keeps outstanding across phases.  Global memory needs no
+// ordering here (the hand-off is data-tagged); where an LDS-DMA result must be visible, an explicit s_waitcnt vmcnt(N)
+// precedes the barrier.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 template <int H, int NBT, int RTW>
 __global__ __launch_bounds__(256, 1) void lstm_layer_granule_kernel(PersistArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int NTH = 256, KS = H / 32, ROWB = H * 2 + 16, RM = 4 * H / 8;
+    constexpr int PF = NBT == 1 ? 0 : (NBT == 2 ? 1 : 2);          // where the next phase's sweep is requested (see above)
     static_assert(RM == 4 * RTW * 16, "4 waves x RTW row tiles must cover the workgroup's gate rows");
     unsigned char *Ph = smem, *Pl = smem + (size_t)16 * ROWB;      // the active tile's h panel, hi / lo planes
     constexpr int UW = RM / 4;                                      // units this workgroup owns (a 2*UW-byte run per output row and plane)
     unsigned short *Oh = reinterpret_cast<unsigned short *>(smem + (size_t)2 * 16 * ROWB), *Ol = Oh + 16 * UW;   // step outputs, [row][unit]
     float *Of = reinterpret_cast<float *>(Ol + 16 * UW);
     unsigned int *Og = reinterpret_cast<unsigned int *>(Of + 16 * UW);   // this step's h as tagged words, [row][unit]
-    static_assert(UW % 8 == 0, "output rows must be whole 16-byte chunks");
+    float *Gx = reinterpret_cast<float *>(Og + 16 * UW);            // [NBT][2 step parities][16 rows][UW units][4 gates] gate pre-activations (LDS-DMA)
+    constexpr int GXT = 16 * UW * 4;                                // floats per tile slab
+    unsigned char *Rw = reinterpret_cast<unsigned char *>(Gx + NBT * 2 * GXT);   // PF > 0: raw granules of the sweep requested ahead (LDS-DMA)
+    static_assert(UW % 8 == 0 && (16 * UW) % NTH == 0, "output rows are whole 16-byte chunks; the gx slab is whole 1 KB wave loads");
     __shared__ int s_fail;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, kq = lane >> 4;
@@ -558,66 +575,100 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_granule_kernel(PersistArgs 
     // rows past the team's real batch rows are never published nor swept: their panel rows stay zero
     constexpr int NLD = 16 * H / 4 / NTH;                          // 16-byte chunks (2 granules = 4 units) per thread and tile
     static_assert(16 * H / 4 % NTH == 0 && H % 4 == 0, "panel must be whole passes of the workgroup");
-    unsigned need0[NBT];
+    int prow[NLD], pdst[NLD];                                       // chunk i of this thread: panel row, byte offset in a plane
 #pragma unroll
-    for (int bt = 0; bt < NBT; bt++) {
-        need0[bt] = 0;
-#pragma unroll
-        for (int i = 0; i < NLD; i++) need0[bt] |= (bt * 16 + (4 * (tid + NTH * i)) / H < a.BGr ? 1u : 0u) << i;
+    for (int i = 0; i < NLD; i++) {
+        const int q = tid + NTH * i;
+        prow[i] = (4 * q) / H;
+        pdst[i] = prow[i] * ROWB + (4 * q - prow[i] * H) * 2;
     }
     for (int i = tid; i < 2 * 16 * ROWB / 4; i += NTH) reinterpret_cast<unsigned int *>(smem)[i] = 0u;
     u64 *hxg = reinterpret_cast<u64 *>(a.hx);
     unsigned int *abortf = a.sync + 16;
     long long ph[6] = {0, 0, 0, 0, 0, 0}, tst = a.dbg ? (long long)__builtin_readcyclecounter() : 0;
-    __syncthreads();
 
-    // A step's critical path is sweep-complete -> MFMA -> cell -> publish; whatever else a step must issue (the layer
-    // outputs, the next gate pre-activations) is placed where the workgroup is not on that chain: the outputs of the
-    // previous phase leave right behind the first sweep pass, the gate pre-activations are requested a whole step ahead.
-    float4 g4[RTW][NBT], g4n[RTW][NBT];
-    auto load_gx = [&](float4 (&dstg)[RTW][NBT], int bt, int tt) {
+    // gate pre-activations of (tile bt, time tt) -> Gx[bt]: each wave-instruction lands 1 KB lane-linear in LDS; the
+    // workgroup's slice of a gx row is one contiguous run of 4*UW floats (gate columns are unit-major)
+    // (slot = (unit + row) mod UW inside a row: the 16 lanes that read one unit of 16 rows then hit 16 different bank groups)
+    constexpr int NGX = 16 * UW / NTH;                              // 1 KB wave loads per slab and wave
+    int grow[4], gcol[4];                                           // (literal bound: a dependent one breaks the host-side instantiation)
+    static_assert(NGX <= 4, "slab chunk table");                                       // slab chunk i of this thread: row, float offset of its unit in a gx row
 #pragma unroll
-        for (int rt = 0; rt < RTW; rt++) {
-            const int lb = bt * 16 + li, b = g * a.BGr + lb;
-            const bool valid = lb < a.BGr && b < B;
-            const float4 v = valid ? *reinterpret_cast<const float4 *>(a.gx + (((size_t)tt * B + b) * 2 + d) * 4 * H + unit[rt] * 4)
-                                   : make_float4(0.f, 0.f, 0.f, 0.f);
-            if (bt == 0) dstg[rt][0] = v; else dstg[rt][NBT - 1] = v;
+    for (int i = 0; i < NGX; i++) {
+        const int e = i * NTH + tid, r = e / UW, slot = e - r * UW, c = slot - r < 0 ? slot - r + UW : slot - r;
+        grow[i] = r; gcol[i] = (d * 4 * H) + (member * UW + c) * 4;
+    }
+    auto load_gx = [&](int bt, int par, int tt) {
+        const float *gbase = a.gx + (size_t)tt * B * 2 * 4 * H;
+#pragma unroll
+        for (int i = 0; i < NGX; i++) {
+            const int b = min(g * a.BGr + min(bt * 16 + grow[i], a.BGr - 1), B - 1);     // rows past the batch read a valid row (never used)
+            __builtin_amdgcn_global_load_lds(gbase + (size_t)b * 2 * 4 * H + gcol[i], (lds_void_t *)(Gx + (bt * 2 + par) * GXT + (i * NTH + wave * 64) * 4), 16, 0, 0);
         }
     };
-    // Layer outputs leave through an LDS tile: the cell update drops its (row, unit) values there, and after the next
-    // barrier the workgroup writes each output row's run as 16-byte chunks (a lane-per-unit store would be 2-byte
-    // pieces over 16 rows: ~24 issue-bound store instructions per step instead of 3).
-    auto store_out = [&](int bt, int tt) {
+    // Every wave issues exactly one store instruction per plane set (48 lanes x 16 bytes each; lanes of rows past the
+    // batch repeat the tile's last valid row: identical bytes to the same address), so that the number of memory
+    // operations a wave issues after a sweep request is known exactly -- see the counted wait below.
+    auto tile_rows = [&](int bt) { const int nv = min(a.BGr, B - g * a.BGr) - bt * 16; return nv < 0 ? 0 : (nv > 16 ? 16 : nv); };
+    auto store_out = [&](int bt, int tt) -> int {
         constexpr int CH = UW / 8, CF = UW / 4;                       // 16-byte chunks per row: bf16 planes, fp32
+        const int nv = tile_rows(bt);
+        if (nv == 0) return 0;
+        int issued = 0;
         if (a.out_split.hi) {
-            for (int q = tid; q < 2 * 16 * CH; q += NTH) {
-                const int pl = q >= 16 * CH, qq = pl ? q - 16 * CH : q, r = qq / CH, c = qq - r * CH, lb = bt * 16 + r, b = g * a.BGr + lb;
-                if (lb < a.BGr && b < B) {
-                    const u32x4 v = *reinterpret_cast<const u32x4 *>((pl ? Ol : Oh) + r * UW + c * 8);
-                    *reinterpret_cast<u32x4 *>((pl ? a.out_split.lo : a.out_split.hi) + ((size_t)tt * B + b) * 2 * H + d * H + member * UW + c * 8) = v;
-                }
+            constexpr int PW = 2 * 16 * CH / 4;                       // chunks per wave (both planes over the 4 waves)
+            if (lane < PW) {
+                const int q = wave * PW + lane, pl = q >= 16 * CH, qq = pl ? q - 16 * CH : q, r = min(qq / CH, nv - 1), c = qq % CH;
+                const int b = g * a.BGr + bt * 16 + r;
+                const u32x4 v = *reinterpret_cast<const u32x4 *>((pl ? Ol : Oh) + r * UW + c * 8);
+                *reinterpret_cast<u32x4 *>((pl ? a.out_split.lo : a.out_split.hi) + ((size_t)tt * B + b) * 2 * H + d * H + member * UW + c * 8) = v;
             }
+            issued++;
         }
         if (a.out_raw) {
-            for (int q = tid; q < 16 * CF; q += NTH) {
-                const int r = q / CF, c = q - r * CF, lb = bt * 16 + r, b = g * a.BGr + lb;
-                if (lb < a.BGr && b < B)
-                    *reinterpret_cast<u32x4 *>(a.out_raw + ((size_t)tt * B + b) * 2 * H + d * H + member * UW + c * 4) =
-                        *reinterpret_cast<const u32x4 *>(Of + r * UW + c * 4);
+            constexpr int PW = 16 * CF / 4;
+            if (lane < PW) {
+                const int q = wave * PW + lane, r = min(q / CF, nv - 1), c = q % CF, b = g * a.BGr + bt * 16 + r;
+                *reinterpret_cast<u32x4 *>(a.out_raw + ((size_t)tt * B + b) * 2 * H + d * H + member * UW + c * 4) =
+                    *reinterpret_cast<const u32x4 *>(Of + r * UW + c * 4);
             }
+            issued++;
+        }
+        return issued;
+    };
+    // first-pass sweep request of (tile bt, step s): every chunk, unconditionally.  With one tile it goes to registers and
+    // is consumed at once.  Otherwise it is issued a phase ahead by LDS-DMA into the staging buffer (no registers held
+    // across the phase, and no compiler-inserted s_waitcnt vmcnt(0) at the point of use: the wave's memory counter is
+    // in-order, so waiting for the request with vmcnt(0) would also wait for the acknowledgement of every store issued
+    // after it -- the write-through publish alone takes ~1 us).  The request is waited for with vmcnt(K), K = the
+    // exact number of memory instructions this wave has issued since.
+    u32x4 pv[NLD];
+    auto request_sweep = [&](int bt, int s) {
+        const u64 *srcp = hxg + (size_t)(((s - 1) & 1) * 32 + team) * pgran + bt * tgran;
+        if (PF == 0) {
+            const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<u64 *>(srcp), 0, (int)(tgran * 8), 0x00020000);
+#pragma unroll
+            for (int i = 0; i < NLD; i++) pv[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (tid + NTH * i) * 16, 0, 16 /* sc1 */);
+        } else {
+#pragma unroll
+            for (int i = 0; i < NLD; i++)
+                __builtin_amdgcn_global_load_lds(reinterpret_cast<const unsigned char *>(srcp) + (size_t)(tid + NTH * i) * 16,
+                                                 (lds_void_t *)(Rw + (size_t)(i * NTH + wave * 64) * 16), 16, 0, 16 /* sc1 */);
         }
     };
 #pragma unroll
-    for (int bt = 0; bt < NBT; bt++) {
-        load_gx(g4, bt, d ? (T - 1) : 0);
-        if (T > 1) load_gx(g4n, bt, d ? (T - 2) : 1);
-    }
-    int pend_bt = -1, pend_t = 0;                                   // the phase whose outputs still sit in the LDS tiles
+    for (int bt = 0; bt < NBT; bt++) load_gx(bt, 0, d ? (T - 1) : 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    lds_barrier();
+
+    int pend_bt = -1, pend_t = 0;                                   // PF == 0: the phase whose outputs still sit in the LDS tiles
+    bool requested = false;                                         // the first pass of the phase about to start is in flight / staged
+    int younger = 0;                                                // memory instructions this wave issued after that request
     for (int s = 0; s < T; s++) {
         const int t = d ? (T - 1 - s) : s;
 #pragma unroll
         for (int bt = 0; bt < NBT; bt++) {
+            const int nbt = bt + 1 < NBT ? bt + 1 : 0, ns = bt + 1 < NBT ? s : s + 1;     // the next phase
             f32x4 acc[RTW];
 #pragma unroll
             for (int rt = 0; rt < RTW; rt++) acc[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -625,32 +676,52 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_granule_kernel(PersistArgs 
                 // ---- sweep this thread's share of the tile's panel (parity (s-1)&1) until every tag is step s-1's
                 const u64 *srcp = hxg + (size_t)(((s - 1) & 1) * 32 + team) * pgran + bt * tgran;
                 const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<u64 *>(srcp), 0, (int)(tgran * 8), 0x00020000);
-                unsigned need = need0[bt];
-                const unsigned ep = (unsigned)((s - 1) % 3 + 1), e0 = (ep & 1u) << 16, e1 = (ep >> 1) << 16;   // tag of step s-1
+                unsigned need = 0;
+                {
+                    const int nvr = a.BGr - bt * 16;                   // rows of this tile that exist in the team's batch group
+#pragma unroll
+                    for (int i = 0; i < NLD; i++) need |= (prow[i] < nvr ? 1u : 0u) << i;
+                }
+                const unsigned ep = (unsigned)((s - 1) % 3 + 1), etag = (ep & 1u) | ((ep >> 1) << 16);   // tag of step s-1: bit 0 in lo0, bit 1 in lo1
                 int sweeps = 0;
                 const long long t0 = wall_clock64();
-                bool first = true;
+                if (!requested) {
+                    if (PF == 0) {
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // own publish acknowledged: a request sent earlier only finds stale tags
+                        request_sweep(bt, s);
+                        if (pend_bt >= 0) store_out(pend_bt, pend_t);   // the previous phase's outputs, behind the sweep in the queue
+                    } else {
+                        const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<u64 *>(srcp), 0, (int)(tgran * 8), 0x00020000);
+#pragma unroll
+                        for (int i = 0; i < NLD; i++) pv[i] = __builtin_amdgcn_raw_buffer_load_b128(rs0, (tid + NTH * i) * 16, 0, 16 /* sc1 */);
+                    }
+                } else {   // requested a phase ago by LDS-DMA: each lane reads back the chunks its own lane position fetched
+                    switch (younger) {
+                        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+                        case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+                        case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+                        default: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+                    }
+#pragma unroll
+                    for (int i = 0; i < NLD; i++) pv[i] = *reinterpret_cast<const u32x4 *>(Rw + (size_t)(i * NTH + tid) * 16);
+                }
+                requested = false;
                 while (true) {
-                    u32x4 pv[NLD];
 #pragma unroll
-                    for (int i = 0; i < NLD; i++)
-                        if (need & (1u << i)) pv[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (tid + NTH * i) * 16, 0, 16 /* sc1 */);
-                    if (first) { if (pend_bt >= 0) store_out(pend_bt, pend_t); first = false; }   // the previous phase's outputs, behind the sweep in the queue
-#pragma unroll
-                    for (int i = 0; i < NLD; i++)
-                        if ((need & (1u << i)) && (pv[i][0] & 0x10000u) == e0 && (pv[i][1] & 0x10000u) == e1 &&
-                            (pv[i][2] & 0x10000u) == e0 && (pv[i][3] & 0x10000u) == e1) {
+                    for (int i = 0; i < NLD; i++) {
+                        // words (unit pairs): [hi0 | lo0'], [hi1 | lo1'] -> hi plane [hi0 | hi1], lo plane [lo0 | lo1] & ~tag bits
+                        const unsigned h0 = __builtin_amdgcn_perm(pv[i][1], pv[i][0], 0x05040100u), l0 = __builtin_amdgcn_perm(pv[i][1], pv[i][0], 0x07060302u);
+                        const unsigned h1 = __builtin_amdgcn_perm(pv[i][3], pv[i][2], 0x05040100u), l1 = __builtin_amdgcn_perm(pv[i][3], pv[i][2], 0x07060302u);
+                        if ((need & (1u << i)) && (l0 & 0x00010001u) == etag && (l1 & 0x00010001u) == etag) {
                             need &= ~(1u << i);
-                            const int q = tid + NTH * i, row = (4 * q) / H, k = 4 * q - row * H;
                             u32x2 vh, vl;
-                            vh[0] = (pv[i][0] & 0xffffu) | (pv[i][1] << 16); vh[1] = (pv[i][2] & 0xffffu) | (pv[i][3] << 16);
-                            vl[0] = ((pv[i][0] >> 16) & 0xfffeu) | (pv[i][1] & 0xfffe0000u);
-                            vl[1] = ((pv[i][2] >> 16) & 0xfffeu) | (pv[i][3] & 0xfffe0000u);
-                            *reinterpret_cast<u32x2 *>(Ph + row * ROWB + k * 2) = vh;
-                            *reinterpret_cast<u32x2 *>(Pl + row * ROWB + k * 2) = vl;
+                            vh[0] = h0; vh[1] = h1; vl[0] = l0 & 0xfffefffeu; vl[1] = l1 & 0xfffefffeu;
+                            *reinterpret_cast<u32x2 *>(Ph + pdst[i]) = vh;
+                            *reinterpret_cast<u32x2 *>(Pl + pdst[i]) = vl;
                         }
+                    }
                     ++sweeps;
-                    if (a.dbg && sweeps == 1) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); ph[1] += (long long)__builtin_readcyclecounter() - tst; }
+                    if (a.dbg && sweeps == 1) ph[1] += (long long)__builtin_readcyclecounter() - tst;   // first pass processed
                     if (__all(need == 0)) break;
                     if ((sweeps & 63) == 0) {
                         int bad = 0;
@@ -660,16 +731,18 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_granule_kernel(PersistArgs 
                             break;
                         }
                     }
+#pragma unroll
+                    for (int i = 0; i < NLD; i++)
+                        if (need & (1u << i)) pv[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (tid + NTH * i) * 16, 0, 16 /* sc1 */);
                 }
-                __syncthreads();
+                lds_barrier();
                 PSTAMP(0);
                 if (a.dbg) ph[5] += sweeps;
                 if (s_fail) return;
-                // gate pre-activations: this step's were requested a whole step ago (right here); request the next step's
-                // now, behind the sweep in the wave's in-order memory queue and with a full step to land
-#pragma unroll
-                for (int rt = 0; rt < RTW; rt++) g4[rt][bt] = g4n[rt][bt];
-                if (s + 1 < T) load_gx(g4n, bt, d ? (T - 2 - s) : (s + 1));
+                // this tile's next gx slab: into the other parity buffer, ahead of the sweep request below in the memory queue
+                // (the request's data is waited for with vmcnt(0): nothing slow may be younger than it)
+                if (s + 1 < T) load_gx(bt, (s + 1) & 1, d ? (T - 2 - s) : (s + 1));
+                if (PF == 2 && ns < T) { request_sweep(nbt, ns); requested = true; }   // that panel was published a whole phase ago
                 // h fragments: PD reads ahead of the MFMAs that use them (a lone wave per SIMD hides no LDS latency otherwise)
                 constexpr int PD = 3;
                 bf16x8 qh[PD], ql[PD];
@@ -699,8 +772,15 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_granule_kernel(PersistArgs 
                     for (int rt = 0; rt < RTW; rt++) acc[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[rt][ks], bh, acc[rt], 0, 0, 0);
                     __builtin_amdgcn_sched_barrier(0);
                 }
-                __syncthreads();   // every wave is done with the LDS panel before the next sweep overwrites it
+                if (PF == 1 && ns < T) {   // two tiles: the other tile's panel has had the length of these MFMAs to arrive
+                    request_sweep(nbt, ns); requested = true;
+                    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NLD) : "memory");   // this tile's gx slab (older) has landed
+                } else {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                lds_barrier();   // every wave is done with the LDS panel; every wave's part of the gx slab is in LDS
             }
+            if (s == 0 && T > 1) load_gx(bt, 1, d ? (T - 2) : 1);
             PSTAMP(2);
             // ---- cell update; h_s goes to the LDS tiles (outputs, and tagged words for the team)
             const unsigned tg = (unsigned)(s % 3 + 1), t0b = (tg & 1u) << 16, t1b = (tg >> 1) << 16;
@@ -708,12 +788,14 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_granule_kernel(PersistArgs 
             for (int rt = 0; rt < RTW; rt++) {
                 const int lb = bt * 16 + li, b = g * a.BGr + lb;
                 const bool valid = lb < a.BGr && b < B;
-                const float ig = fast_sigmoid(acc[rt][0] + g4[rt][bt].x), fg = fast_sigmoid(acc[rt][1] + g4[rt][bt].y);
-                const float cg = fast_tanh(acc[rt][2] + g4[rt][bt].z), og = fast_sigmoid(acc[rt][3] + g4[rt][bt].w);
+                const int ul = (wave * RTW + rt) * 4 + kq;
+                const int gslot = ul + li >= UW ? ul + li - UW : ul + li;
+                const float4 gv = *reinterpret_cast<const float4 *>(Gx + (bt * 2 + (s & 1)) * GXT + (li * UW + gslot) * 4);
+                const float ig = fast_sigmoid(acc[rt][0] + gv.x), fg = fast_sigmoid(acc[rt][1] + gv.y);
+                const float cg = fast_tanh(acc[rt][2] + gv.z), og = fast_sigmoid(acc[rt][3] + gv.w);
                 const float cn = fg * cst[rt][bt] + ig * cg;
                 const float hn = valid ? og * fast_tanh(cn) : 0.f;
                 cst[rt][bt] = cn;
-                const int ul = (wave * RTW + rt) * 4 + kq;
                 const float ov = hn * osc[rt] + osh[rt];
                 __bf16 ob = (__bf16)ov, ol = (__bf16)(ov - (float)ob);
                 Oh[li * UW + ul] = *reinterpret_cast<unsigned short *>(&ob);
@@ -721,40 +803,43 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_granule_kernel(PersistArgs 
                 Of[li * UW + ul] = hn;
                 Og[li * UW + ul] = split_h(hn) | ((kq & 1) ? t1b : t0b);   // even unit: tag bit 0, odd unit: bit 1
             }
-            pend_bt = bt; pend_t = t;
             PSTAMP(3);
-            __syncthreads();                                         // the tiles are complete
+            lds_barrier();                                         // the tiles are complete; the gx slab is consumed
             // ---- publish h_s (no drain, no signal): the workgroup's slice of every row is one 4*UW-byte run of whole
             // 64-byte lines, written as 16-byte write-through stores (a lane-per-unit store is 16 partial lines per
-            // instruction, and the sweep that follows in the same in-order queue waits for every acknowledgement)
-            if (s + 1 < T) {
+            // instruction, and a sweep that follows in the same in-order queue waits for every acknowledgement)
+            younger = 0;
+            if (s + 1 < T) {   // all 16 rows of the tile (rows past the batch carry zeros and valid tags; nobody sweeps them)
                 const __amdgpu_buffer_rsrc_t drs = __builtin_amdgcn_make_buffer_rsrc(hxg + (size_t)((s & 1) * 32 + team) * pgran + bt * tgran, 0, (int)(tgran * 8), 0x00020000);
-                constexpr int CG = UW / 4;                             // 16-byte chunks per row
-                for (int q = tid; q < 16 * CG; q += NTH) {
-                    const int r = q / CG, c = q - r * CG;
-                    if (bt * 16 + r < a.BGr)
-                        __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4 *>(Og + r * UW + c * 4), drs,
-                                                               (r * (H / 2) + member * (UW / 2)) * 8 + c * 16, 0, 16 /* sc1 */);
+                constexpr int CG = UW / 4, PW = 16 * CG / 4;           // 16-byte chunks per row; chunks per wave
+                if (lane < PW) {
+                    const int q = wave * PW + lane, r = q / CG, c = q - r * CG;
+                    __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4 *>(Og + r * UW + c * 4), drs,
+                                                           (r * (H / 2) + member * (UW / 2)) * 8 + c * 16, 0, 16 /* sc1 */);
                 }
+                younger++;
             }
-            if (s == 0) {   // no sweep follows for the other tiles' first step: flush the tiles now
-                store_out(bt, t);
-                pend_bt = -1;
-                __syncthreads();
+            // layer outputs: with one tile they wait for the next sweep's request (nothing else to hide them behind);
+            // otherwise the next sweep is already in flight and they go out now
+            if (PF == 0 && s > 0 && s + 1 < T) { pend_bt = bt; pend_t = t; }
+            else { younger += store_out(bt, t); pend_bt = -1; }
+            if (s == 0) {   // no MFMA section with its barriers follows before these LDS regions are reused
+                if (bt + 1 == NBT) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                lds_barrier();
             }
             PSTAMP(4);
         }
     }
-    if (pend_bt >= 0) store_out(pend_bt, pend_t);                   // the last phase's outputs (the others left during the next sweep)
+    if (pend_bt >= 0) store_out(pend_bt, pend_t);
     if (a.dbg && tid == 0) for (int i = 0; i < 6; i++) a.dbg[blockIdx.x * 6 + i] = ph[i];
 }
 
-int granule_bg(int B) { const int r = (B + 15) / 16; return r <= 16 ? 16 : 32; }   // rows per batch group (16 groups), padded
+int granule_bg(int B) { const int r = (B + 15) / 16; return (r + 15) / 16 * 16; }   // rows per batch group (16 groups), padded to whole tiles
 
 template <int H, int NBT, int RTW>
 static int launch_granule_t(PersistArgs a, hipStream_t st) {
     constexpr int ROWB = H * 2 + 16;
-    const size_t smem = (size_t)2 * 16 * ROWB + (size_t)16 * (H / 8) * 12;   // one tile's h panel + tiles (2 bf16 planes + fp32 + tagged h words)
+    const size_t smem = (size_t)2 * 16 * ROWB + (size_t)16 * (H / 8) * 12 + (size_t)NBT * 2 * 16 * (H / 8) * 16 + (NBT > 1 ? (size_t)16 * H * 4 : 0);   // h panel + tiles (2 bf16 planes, fp32, tagged words) + gx slabs (2 parities) + sweep staging
     MDD_HIP_CHECK(hipMemsetAsync(a.sync, 0, 32 * sizeof(unsigned int), st));
     MDD_HIP_CHECK(hipMemsetAsync(a.hx, 0, (size_t)2 * 32 * NBT * 16 * H * 4, st));   // tags must start at 0 on every launch
     hipLaunchKernelGGL((lstm_layer_granule_kernel<H, NBT, RTW>), dim3(256), dim3(256), smem, st, a);
@@ -771,15 +856,18 @@ int launch_lstm_layer_granule(const LstmStepArgs &s, unsigned short *hx, unsigne
     if (a.oscale == nullptr) a.oshift = nullptr;
     if (a.out && a.out != a.out_raw) { set_error("granule lstm: a separate scaled fp32 output is not supported (split planes carry it)"); return MDD_ERR_ARG; }
     const int nbt = a.BG / 16;
-    if (s.H == 384) return nbt == 1 ? launch_granule_t<384, 1, 3>(a, st) : launch_granule_t<384, 2, 3>(a, st);
-    if (s.H == 256) return nbt == 1 ? launch_granule_t<256, 1, 2>(a, st) : launch_granule_t<256, 2, 2>(a, st);
+    if (nbt < 1 || nbt > 4) { set_error("granule lstm: B=%d needs %d row tiles per team (max 4)", s.B, nbt); return MDD_ERR_ARG; }
+    if (s.H == 384) return nbt == 1 ? launch_granule_t<384, 1, 3>(a, st) : nbt == 2 ? launch_granule_t<384, 2, 3>(a, st)
+                         : nbt == 3 ? launch_granule_t<384, 3, 3>(a, st) : launch_granule_t<384, 4, 3>(a, st);
+    if (s.H == 256) return nbt == 1 ? launch_granule_t<256, 1, 2>(a, st) : nbt == 2 ? launch_granule_t<256, 2, 2>(a, st)
+                         : nbt == 3 ? launch_granule_t<256, 3, 2>(a, st) : launch_granule_t<256, 4, 2>(a, st);
     set_error("granule lstm: unsupported H=%d", s.H);
     return MDD_ERR_ARG;
 }
 
 int init_granule_attributes() {
-#define GATTR(H, N, R) MDD_HIP_CHECK(hipFuncSetAttribute((const void *)lstm_layer_granule_kernel<H, N, R>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024))
-    GATTR(384, 1, 3); GATTR(384, 2, 3); GATTR(256, 1, 2); GATTR(256, 2, 2);
+#define GATTR(H, N, R) MDD_HIP_CHECK(hipFuncSetAttribute((const void *)lstm_layer_granule_kernel<H, N, R>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024))
+    GATTR(384, 1, 3); GATTR(384, 2, 3); GATTR(384, 3, 3); GATTR(384, 4, 3); GATTR(256, 1, 2); GATTR(256, 2, 2); GATTR(256, 3, 2); GATTR(256, 4, 2);
 #undef GATTR
     return MDD_OK;
 }

@@ -251,10 +251,10 @@ def test_forward_edge_shapes_against_oracle(B, T, L, precision):
     np.testing.assert_allclose(got, oracle.forward(sd, x, x1), rtol=0, atol=TOL)
 
 
-@pytest.mark.parametrize("B", [100, 256, 300, 512])
+@pytest.mark.parametrize("B", [100, 256, 300, 512, 700, 1000])
 def test_persistent_lstm_batch_sizes_match_step_kernels(B, monkeypatch):
-    """Every team geometry of the persistent BiLSTM (granule form for B <= 256, counter form above) against the
-    per-step split-bf16 kernels, bit for bit; short sequence, full width."""
+    """Every team geometry of the persistent BiLSTM (1 to 4 row tiles per team in the granule form, and the counter
+    form) against the per-step split-bf16 kernels, bit for bit; short sequence, full width."""
     geom = synth.Geometry(**synth.REFERENCE)
     sd = synth.synth_state_dict(geom, seed=77)
     x, x1, _, _ = synth.synth_batch(geom, B=B, T=40, L=6, seed=B, ragged=True)
@@ -263,9 +263,10 @@ def test_persistent_lstm_batch_sizes_match_step_kernels(B, monkeypatch):
     monkeypatch.delenv("MDD_LSTM")
     got = _hip().HipModel(geom, sd, precision="bf16x3").forward(_cuda(x), _cuda(x1), sync_errors=True).cpu().numpy()
     np.testing.assert_array_equal(got, ref)
-    monkeypatch.setenv("MDD_LSTM", "counter")
-    got2 = _hip().HipModel(geom, sd, precision="bf16x3").forward(_cuda(x), _cuda(x1), sync_errors=True).cpu().numpy()
-    np.testing.assert_array_equal(got2, ref)
+    if B <= 512:                                   # the counter form covers up to 64 rows per 8-row group
+        monkeypatch.setenv("MDD_LSTM", "counter")
+        got2 = _hip().HipModel(geom, sd, precision="bf16x3").forward(_cuda(x), _cuda(x1), sync_errors=True).cpu().numpy()
+        np.testing.assert_array_equal(got2, ref)
 
 
 def test_decoders_edge_cases_against_oracle():
