@@ -241,6 +241,8 @@ def main():
                 "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic,
                 "note": ("algorithmic fp32-equivalent flops; the split-bf16 kernels issue 3 bf16 MFMA flops per algorithmic flop "
                          "(frac x3 = matrix-core utilisation)" if bf16_kernel else "fp32 MFMA"),
+                "matrix_core_frac": round(achieved * (3 if bf16_kernel else 1) / peak, 4),
+                "frac_of_fp32_mfma_peak": round(achieved / PEAK_F32_MATRIX_TFLOPS, 3),
                 "launches_per_pass": launches, "avg_launch_us": round(ms * 1e3 / max(launches, 1), 3), "batches_per_pass": G,
                 "flops_per_launch": flops / max(launches, 1),
                 "kernel_classes_ms": {k: round(v[0], 4) for k, v in groups.items()},

@@ -335,9 +335,9 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16x3_glds256_kernel(const unsig
 #pragma unroll
             for (int j = 0; j < 4; j++) acc16[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
-    auto fill = [&](int k0, unsigned char *stage) {
+    auto fill = [&](int k0, unsigned char *stage, int j0 = 0, int j1 = 8) {
 #pragma unroll
-        for (int j = 0; j < 8; j++) {
+        for (int j = j0; j < j1; j++) {
             const int id = j * 8 + wave, p = id >> 4, g = id & 15;
             const int row = g * 16 + (lane >> 2), cp = lane & 3, c = cp ^ ((row >> 2) & 3);
             const unsigned short *base = p == 0 ? Ah : (p == 1 ? Al : (p == 2 ? Wh : Wl));
@@ -352,7 +352,9 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16x3_glds256_kernel(const unsig
     __syncthreads();
     for (int kt = 0; kt < nk; kt++) {
         const int cur = kt & 1;
-        if (kt + 1 < nk) fill((kt + 1) * XBK, glds_smem + (cur ^ 1) * 4 * PL);
+        const bool more = kt + 1 < nk;
+        unsigned char *nst = glds_smem + (cur ^ 1) * 4 * PL;
+        if (SHAPE == 0 && more) fill((kt + 1) * XBK, nst);
         const unsigned char *st = glds_smem + cur * 4 * PL;
         if (SHAPE == 0) {
 #pragma unroll
@@ -383,8 +385,14 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16x3_glds256_kernel(const unsig
                 fwh[j] = x3_frag(st + 2 * PL, wn * 64 + j * 16 + l16, kq16);
                 fwl[j] = x3_frag(st + 3 * PL, wn * 64 + j * 16 + l16, kq16);
             }
+            // the next stage's 8 LDS-DMA pieces go out two at a time between the MFMA groups: a piece costs the issuing
+            // wave 100+ cycles, which the SIMD's other wave covers with MFMAs only if the two are not doing it at once
 #pragma unroll
             for (int i = 0; i < 8; i++) {
+                if ((i & 1) == 0) {
+                    if (more) fill((kt + 1) * XBK, nst, i, i + 2);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
                 const bf16x8 fah = x3_frag(st, wm * 128 + i * 16 + l16, kq16);
                 const bf16x8 fal = x3_frag(st + PL, wm * 128 + i * 16 + l16, kq16);
 #pragma unroll
@@ -393,6 +401,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16x3_glds256_kernel(const unsig
                 for (int j = 0; j < 4; j++) acc16[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fal, fwh[j], acc16[i][j], 0, 0, 0);
 #pragma unroll
                 for (int j = 0; j < 4; j++) acc16[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fah, fwh[j], acc16[i][j], 0, 0, 0);
+                if (i & 1) __builtin_amdgcn_sched_barrier(0);
             }
         }
         __syncthreads();
