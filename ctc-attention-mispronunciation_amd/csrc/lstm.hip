@@ -522,6 +522,20 @@ typedef __attribute__((address_space(3))) void lds_void_t;
 // in-flight LDS-DMA / sweep requests this kernel deliberately keeps outstanding across phases.  Global memory needs no
 // ordering here (the hand-off is data-tagged); where an LDS-DMA result must be visible, an explicit s_waitcnt vmcnt(N)
 // precedes the barrier.
+__device__ __forceinline__ void wait_vmcnt(int n) {   // s_waitcnt vmcnt(n) for a wave-uniform n (the count is an immediate)
+    switch (n) {
+        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+        case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+        case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+        case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+        case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+        case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+        case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;   // n >= 9: waiting for more than asked is always safe
+    }
+}
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 template <int H, int NBT, int RTW>
@@ -598,10 +612,11 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_granule_kernel(PersistArgs 
         const int e = i * NTH + tid, r = e / UW, slot = e - r * UW, c = slot - r < 0 ? slot - r + UW : slot - r;
         grow[i] = r; gcol[i] = (d * 4 * H) + (member * UW + c) * 4;
     }
-    auto load_gx = [&](int bt, int par, int tt) {
+    auto load_gx = [&](int bt, int par, int tt, int i0 = 0, int i1 = 99) {
+        i1 = i1 > NGX ? NGX : i1;
         const float *gbase = a.gx + (size_t)tt * B * 2 * 4 * H;
 #pragma unroll
-        for (int i = 0; i < NGX; i++) {
+        for (int i = i0; i < i1; i++) {
             const int b = min(g * a.BGr + min(bt * 16 + grow[i], a.BGr - 1), B - 1);     // rows past the batch read a valid row (never used)
             __builtin_amdgcn_global_load_lds(gbase + (size_t)b * 2 * 4 * H + gcol[i], (lds_void_t *)(Gx + (bt * 2 + par) * GXT + (i * NTH + wave * 64) * 4), 16, 0, 0);
         }
@@ -643,7 +658,8 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_granule_kernel(PersistArgs 
     // after it -- the write-through publish alone takes ~1 us).  The request is waited for with vmcnt(K), K = the
     // exact number of memory instructions this wave has issued since.
     u32x4 pv[NLD];
-    auto request_sweep = [&](int bt, int s) {
+    auto request_sweep = [&](int bt, int s, int i0 = 0, int i1 = 99) {
+        i1 = i1 > NLD ? NLD : i1;
         const u64 *srcp = hxg + (size_t)(((s - 1) & 1) * 32 + team) * pgran + bt * tgran;
         if (PF == 0) {
             const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<u64 *>(srcp), 0, (int)(tgran * 8), 0x00020000);
@@ -651,7 +667,7 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_granule_kernel(PersistArgs 
             for (int i = 0; i < NLD; i++) pv[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (tid + NTH * i) * 16, 0, 16 /* sc1 */);
         } else {
 #pragma unroll
-            for (int i = 0; i < NLD; i++)
+            for (int i = i0; i < i1; i++)
                 __builtin_amdgcn_global_load_lds(reinterpret_cast<const unsigned char *>(srcp) + (size_t)(tid + NTH * i) * 16,
                                                  (lds_void_t *)(Rw + (size_t)(i * NTH + wave * 64) * 16), 16, 0, 16 /* sc1 */);
         }
@@ -741,8 +757,11 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_granule_kernel(PersistArgs 
                 if (s_fail) return;
                 // this tile's next gx slab: into the other parity buffer, ahead of the sweep request below in the memory queue
                 // (the request's data is waited for with vmcnt(0): nothing slow may be younger than it)
-                if (s + 1 < T) load_gx(bt, (s + 1) & 1, d ? (T - 2 - s) : (s + 1));
-                if (PF == 2 && ns < T) { request_sweep(nbt, ns); requested = true; }   // that panel was published a whole phase ago
+                // The LDS-DMA pieces of this phase -- this tile's next gx slab (other parity buffer), then, with three or more
+                // tiles, the next tile's sweep (its panel was published a whole phase ago) -- are issued one per k-step inside
+                // the MFMA loop: a piece costs the wave ~100 cycles of issue, which the MFMAs in flight cover.  The slab goes
+                // first: nothing slow may be younger than the sweep request (see the counted wait at its consumption).
+                const bool do_gx = s + 1 < T, do_rq = PF == 2 && ns < T;
                 // h fragments: PD reads ahead of the MFMAs that use them (a lone wave per SIMD hides no LDS latency otherwise)
                 constexpr int PD = 3;
                 bf16x8 qh[PD], ql[PD];
@@ -759,6 +778,8 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_granule_kernel(PersistArgs 
                         qh[ks % PD] = *reinterpret_cast<const bf16x8 *>(Ph + li * ROWB + (ks + PD) * 64 + kq * 16);
                         ql[ks % PD] = *reinterpret_cast<const bf16x8 *>(Pl + li * ROWB + (ks + PD) * 64 + kq * 16);
                     }
+                    if (ks < NGX) { if (do_gx) load_gx(bt, (s + 1) & 1, d ? (T - 2 - s) : (s + 1), ks, ks + 1); }
+                    else if (ks < NGX + NLD) { if (do_rq) request_sweep(nbt, ns, ks - NGX, ks - NGX + 1); }
                     // product-major order: consecutive MFMAs hit different accumulators (no dependent-issue stall);
                     // each accumulator still sees ah.bl, al.bh, ah.bh in that order (bit-identical to the step kernel)
                     // (the scheduler would otherwise regroup them per accumulator into dependent back-to-back pairs)
@@ -772,12 +793,14 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_granule_kernel(PersistArgs 
                     for (int rt = 0; rt < RTW; rt++) acc[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[rt][ks], bh, acc[rt], 0, 0, 0);
                     __builtin_amdgcn_sched_barrier(0);
                 }
+                static_assert(NGX + NLD <= KS, "one LDS-DMA piece per k-step");
+                if (do_rq) requested = true;
+                int in_flight = (do_gx ? NGX : 0) + (do_rq ? NLD : 0);
                 if (PF == 1 && ns < T) {   // two tiles: the other tile's panel has had the length of these MFMAs to arrive
                     request_sweep(nbt, ns); requested = true;
-                    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NLD) : "memory");   // this tile's gx slab (older) has landed
-                } else {
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    in_flight += NLD;
                 }
+                wait_vmcnt(in_flight);   // everything older than this phase's pieces has landed: in particular this tile's current gx slab
                 lds_barrier();   // every wave is done with the LDS panel; every wave's part of the gx slab is in LDS
             }
             if (s == 0 && T > 1) load_gx(bt, 1, d ? (T - 2) : 1);
