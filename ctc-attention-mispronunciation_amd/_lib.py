@@ -10,10 +10,12 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmdd_hip.so")
 
+MDD_ERR_EMPTY = -5   # include/mdd_hip.h: an empty sequence where the reference raises TypeError
+
 EXPORTS = (
     "mdd_last_error", "mdd_version", "mdd_create", "mdd_destroy", "mdd_load_weight", "mdd_finalize_weights",
     "mdd_set_precision", "mdd_get_precision", "mdd_stack_len", "mdd_stack_skip", "mdd_len_frames", "mdd_forward", "mdd_forward_num_stages", "mdd_forward_profile", "mdd_tap", "mdd_tap_copy", "mdd_enable_taps", "mdd_sync",
-    "mdd_greedy", "mdd_beam", "mdd_ctc_loss", "mdd_align",
+    "mdd_greedy", "mdd_beam", "mdd_ctc_loss", "mdd_align", "mdd_eval_batch",
 )
 
 
@@ -67,6 +69,7 @@ def lib():
     L.mdd_beam.argtypes = [vp, i32, i32, i32, vp, i32, i32, vp, C.c_double, vp, vp, vp, vp, vp]
     L.mdd_ctc_loss.argtypes = [vp, i32, i32, i32, vp, i32, vp, vp, i32, vp, vp, vp]
     L.mdd_align.argtypes = [vp, i32, vp, i32, C.POINTER(i32), vp, C.POINTER(i32)]
+    L.mdd_eval_batch.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, vp]
     _lib = L
     return L
 

@@ -69,3 +69,13 @@ def decode_sharded(batches, decode_fn, pad_len):
             if k < len(batches):
                 results[k] = (all_ids[src], all_n[src])
     return results
+
+
+def sum_counts(values, device=None):
+    """All-reduce (sum) of a rank's evaluation tallies (`steps.test_ctc_nosil.MddCounts.as_list()`, 8 integers): every
+    rank gets the totals of the whole job -- the only exchange the batch evaluation needs (SURVEY 8(f) #2)."""
+    t = torch.tensor([int(v) for v in values], dtype=torch.int64, device=device)
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return [int(v) for v in t.tolist()]
+

@@ -137,6 +137,14 @@ int mdd_ctc_loss(const float *logp_dev, int32_t T, int32_t B, int32_t C, const i
 int mdd_align(const int32_t *a, int32_t na, const int32_t *b, int32_t nb, int32_t *dist, uint8_t *ops,
               int32_t *nops);
 
+/* ---- evaluation counts of a batch (AA/steps/test_ctc_nosil.py:33-60,218-298), host.
+ * Row x of dec / lab / can (row pitch `stride` ids) holds the decoded, annotated and canonical phoneme ids of utterance x
+ * with 'sil' already removed (:196-209).  counts[8] = { phonemes in canonical, TA, FR, FA, TR correctly diagnosed,
+ * TR wrongly diagnosed, sum of edit distances decoded vs annotated, annotated phonemes }.  Any empty sequence ->
+ * MDD_ERR_EMPTY (the reference's loop dies with TypeError there). */
+int mdd_eval_batch(const int32_t *dec, const int32_t *dec_len, const int32_t *lab, const int32_t *lab_len,
+                   const int32_t *can, const int32_t *can_len, int32_t n, int32_t stride, int64_t *counts);
+
 #ifdef __cplusplus
 }
 #endif

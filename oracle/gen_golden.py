@@ -35,6 +35,7 @@ AA = "/root/reference/egs/attention_aug"
 OUT = os.path.join(ROOT, "tests", "golden")
 sys.path.insert(0, os.path.join(ROOT, "ctc-attention-mispronunciation_amd"))
 import synth  # noqa: E402
+sys.path.pop(0)   # the package mirrors the reference's module names (models/, utils/): keep it off the path from here on
 
 if not os.path.isdir(AA):
     sys.exit("reference tree not present: goldens can only be regenerated in the build container")
@@ -338,6 +339,107 @@ def gen_align_goldens():
     print("G4/G7 align: %d pairs; empties ->" % len(recs), [e["error"] for e in empties])
 
 
+# ----------------------------------------------------------------------------- G8 (batch evaluation counts)
+def load_eval_pieces():
+    """From AA/steps/test_ctc_nosil.py take, by ast and without running the module: the helper
+    `print_align_space_canonical_origin` (:33-82) and, out of `test()`, the two per-batch loops that strip 'sil'
+    (:196-209) and that count TA / FR / FA / TR (:218-298).  They are executed as they stand, in a namespace we fill."""
+    src = open(os.path.join(AA, "steps", "test_ctc_nosil.py")).read()
+    tree = ast.parse(src)
+    helper = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == "print_align_space_canonical_origin"]
+    test_fn = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == "test"][0]
+    loops = {}
+    for node in ast.walk(test_fn):
+        if isinstance(node, ast.For) and isinstance(node.iter, ast.Call) and isinstance(node.target, ast.Name):
+            txt = ast.unparse(node.iter)
+            if node.target.id == "i" and txt == "range(len(labels))":
+                loops["strip"] = node
+            if node.target.id == "x" and txt == "range(len(labels_nosil))":
+                loops["count"] = node
+    assert set(loops) == {"strip", "count"}, loops.keys()
+    ns = {}
+    exec(compile(ast.Module(body=helper, type_ignores=[]), "test_ctc_nosil.py<helper>", "exec"), ns)
+    code = {k: compile(ast.Module(body=[v], type_ignores=[]), "test_ctc_nosil.py<%s loop>" % k, "exec") for k, v in loops.items()}
+    return ns, code
+
+
+def gen_eval_goldens():
+    dec = GreedyDecoder(synth.phone_table_41(), space_idx=-1, blank_index=0)
+    ns, code = load_eval_pieces()
+    units = [synth.phone_table_41()[i] for i in range(3, 44)]
+    rs = np.random.Generator(np.random.PCG64(77))
+
+    def mutate(seq, nmax):
+        out = list(seq)
+        for _ in range(int(rs.integers(0, nmax + 1))):
+            op = int(rs.integers(0, 3))
+            if op == 0 and out:
+                out[int(rs.integers(0, len(out)))] = units[int(rs.integers(0, len(units)))]
+            elif op == 1:
+                pos = int(rs.integers(0, len(out) + 1))
+                for _r in range(int(rs.integers(1, 3))):           # runs of insertions: repeated gap keys
+                    out.insert(pos, units[int(rs.integers(0, len(units)))])
+            elif len(out) > 1:
+                del out[int(rs.integers(0, len(out)))]
+        return out
+
+    def with_sil(seq):
+        out = list(seq)
+        for _ in range(int(rs.integers(0, 3))):
+            out.insert(int(rs.integers(0, len(out) + 1)), "sil")
+        return out
+
+    batches = []
+    for bi in range(12):
+        n = int(rs.integers(3, 9))
+        can, lab, hyp = [], [], []
+        for _ in range(n):
+            c = [units[int(j)] for j in rs.integers(0, 14 if bi % 2 else len(units), size=int(rs.integers(2, 16)))]
+            l = mutate(c, 3)                      # what the speaker actually said (annotation)
+            h = mutate(l if rs.random() < 0.7 else c, 3)   # what the model heard
+            can.append(with_sil(c)); lab.append(with_sil(l)); hyp.append(with_sil(h))
+        env = dict(ns)
+        env.update(decoder=dec, labels=[" ".join(v) for v in lab], decoded=[" ".join(v) for v in hyp],
+                   canonicals=[" ".join(v) for v in can], decoded_nosil=[], labels_nosil=[], canonicals_nosil=[])
+        exec(code["strip"], env)
+        env.update(utt_list=["UTT%02d_%02d" % (bi, i) for i in range(n)], m_speaker=[], test_wrd_dict={},
+                   total_phonemes_in_canonical=0, m_total_phonemes_in_canonical=0, true_accept=0, m_true_accept=0,
+                   false_rejection=0, m_false_rejection=0, false_accept=0, m_false_accept=0,
+                   true_rejection_correct_diagnose=0, m_true_rejection_correct_diagnose=0,
+                   true_rejection_wrong_diagnose=0, m_true_rejection_wrong_diagnose=0, total_wer=0, m_wer=0, m_decoder_num=0)
+        dec.num_word = 0
+        exec(code["count"], env)
+        rec = dict(decoded=env["decoded"], labels=env["labels"], canonicals=env["canonicals"],
+                   decoded_nosil=env["decoded_nosil"], labels_nosil=env["labels_nosil"], canonicals_nosil=env["canonicals_nosil"],
+                   total=int(env["total_phonemes_in_canonical"]), TA=int(env["true_accept"]), FR=int(env["false_rejection"]),
+                   FA=int(env["false_accept"]), TRc=int(env["true_rejection_correct_diagnose"]),
+                   TRw=int(env["true_rejection_wrong_diagnose"]), total_wer=int(env["total_wer"]), num_word=int(dec.num_word))
+        tr = rec["TRc"] + rec["TRw"]
+        try:                                       # test_ctc_nosil.py:310-314
+            pr = float(tr) / (tr + rec["FR"]); rc = float(tr) / (tr + rec["FA"])
+            rec.update(precision=pr * 100, recall=rc * 100, f1=2 * pr * rc / (pr + rc) * 100, error=None)
+        except ZeroDivisionError:
+            rec.update(precision=None, recall=None, f1=None, error="ZeroDivisionError")
+        batches.append(rec)
+    # the helper alone, on a few hand-made paths (keys of the 'I' list, 'S' + phone values)
+    singles = []
+    for hyp, can in ((["aa", "b"], ["aa", "b"]), (["k", "aa", "b", "s"], ["aa", "b"]), (["aa"], ["aa", "b", "k"]),
+                     (["s", "s", "aa", "t", "t"], ["aa", "k", "t"]), (["b"] * 12, ["b"] * 11 + ["k"])):
+        s1, s2 = " ".join(hyp), " ".join(can)
+        _, path = dec.wer(s1, s2)
+        a, b, c, d = ns["print_align_space_canonical_origin"](s1, s2, list(path))
+        singles.append(dict(s1=s1, s2=s2, path=path, out=[a, b, c], d={str(k): v for k, v in d.items()}))
+    # an utterance whose decode is empty: the reference's loop dies with TypeError (ctcDecoder.py:137-138)
+    try:
+        dec.wer("", "aa b")
+        empty_err = None
+    except Exception as e:  # noqa: BLE001
+        empty_err = type(e).__name__
+    json.dump(dict(batches=batches, singles=singles, empty_decode_error=empty_err), open(os.path.join(OUT, "g8_eval.json"), "w"))
+    print("G8 eval: %d batches; totals TA/FR/FA/TRc/TRw =" % len(batches),
+          [sum(b[k] for b in batches) for k in ("TA", "FR", "FA", "TRc", "TRw")], "empty ->", empty_err)
+
+
 # ----------------------------------------------------------------------------- G5
 def gen_ctc_goldens():
     arrays = {}
@@ -409,7 +511,7 @@ def gen_input_goldens():
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ["model", "decode", "align", "ctc", "input"]
+    which = sys.argv[1:] or ["model", "decode", "align", "eval", "ctc", "input"]
     with torch.no_grad():
         if "model" in which:
             gen_model_goldens()
@@ -417,6 +519,8 @@ if __name__ == "__main__":
             gen_decode_goldens()
     if "align" in which:
         gen_align_goldens()
+    if "eval" in which:
+        gen_eval_goldens()
     if "ctc" in which:
         gen_ctc_goldens()
     if "input" in which:

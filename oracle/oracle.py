@@ -202,3 +202,65 @@ def ctc_loss(logp, targets, in_len, tgt_len, blank=0, want_grad=True):
     grad = np.zeros_like(logp) if want_grad else None
     lib().orc_ctc_loss(_p(logp), T, B, Cc, _p(tg), tg.shape[1], _p(il), _p(tl), blank, _p(nll), _p(grad))
     return nll, grad
+
+
+def eval_counts(decoded, labels, canonicals):
+    """SURVEY 8(f) #2 -- CPU restatement of the evaluation bookkeeping of AA/steps/test_ctc_nosil.py:33-60,196-209,
+    218-298 for one batch of space-separated phoneme strings: returns [canonical phonemes, TA, FR, FA, TR correct,
+    TR wrong, summed edit distance decoded-vs-annotated, annotated phonemes].  Small inputs only (pure Python on top of
+    `align`).  An empty sequence raises TypeError, as the reference's `_, path = decoder.wer(...)` does."""
+    def nosil(s):
+        return [t for t in s.split(" ") if t != "sil"]
+
+    def position_map(hyp, can):
+        if not hyp or not can:
+            raise TypeError("cannot unpack non-iterable int object")
+        table = {}
+        dist, ops = align([table.setdefault(t, len(table)) for t in hyp], [table.setdefault(t, len(table)) for t in can])
+        val, gaps, hi, j = {}, [], 0, 0
+        for op in ops:
+            if op == "-":
+                val[j] = "-"; hi += 1; j += 1
+            elif op == "S":
+                val[j] = "S" + hyp[hi]; hi += 1; j += 1
+            elif op == "D":
+                val[j] = "D"; j += 1
+            else:
+                gaps.append(str(j - 1) + str(j)); hi += 1
+        return dist, val, gaps
+
+    out = [0] * 8
+    for dec, lab, can in zip(decoded, labels, canonicals):
+        dec, lab, can = nosil(dec), nosil(lab), nosil(can)
+        _, v1, g1 = position_map(lab, can)
+        err, _, _ = position_map(dec, lab)
+        _, v2, g2 = position_map(dec, can)
+        out[0] += len(can)
+        for j in range(len(can)):
+            a, b = v1[j], v2[j]
+            if a == "-" and b == "-":
+                out[1] += 1
+            elif a == "-":
+                out[2] += 1
+            elif b == "-":
+                out[3] += 1
+            elif a == b:
+                out[4] += 1
+            else:
+                out[5] += 1
+        if g1 and not g2:
+            out[3] += len(g1)
+        elif g2 and not g1:
+            out[2] += len(g2)
+        elif g1 and g2:
+            for e in g1:                      # the reference removes from the list it is iterating: kept, it skips elements
+                if e in g2:
+                    g1.remove(e)
+                    g2.remove(e)
+                    out[4] += 1
+            out[3] += len(g1)
+            out[2] += len(g2)
+        out[6] += err
+        out[7] += len(lab)
+    return out
+

@@ -307,3 +307,38 @@ def test_ctc_edge_cases_against_oracle():
     nll_only, g = _hip().ctc_loss(_cuda(lp), _cuda(tg), _cuda(il), _cuda(tl), want_grad=False)
     assert g is None
     np.testing.assert_array_equal(nll_only.cpu().numpy(), nll.cpu().numpy())
+
+
+def test_batch_evaluation_golden_and_oracle():
+    """SURVEY 8(f) #2 through the C ABI (mdd_eval_batch) and its host mirror: the reference's own counts (G8), the
+    helper's four return values, the exception on an empty decode, and random batches against the oracle."""
+    from ctc_attention_mispronunciation_amd.steps.test_ctc_nosil import (count_batch, print_align_space_canonical_origin,
+                                                                          strip_sil, MddCounts)
+    g = jload("g8_eval.json")
+    keys = ("total", "TA", "FR", "FA", "TRc", "TRw", "total_wer", "num_word")
+    total = MddCounts()
+    for b in g["batches"]:
+        assert strip_sil(b["decoded"]) == b["decoded_nosil"] and strip_sil(b["canonicals"]) == b["canonicals_nosil"]
+        c = count_batch(b["decoded"], b["labels"], b["canonicals"])
+        assert c.as_list() == [b[k] for k in keys], b
+        if b["error"] is None:
+            rep = c.report()
+            np.testing.assert_allclose([rep["precision"], rep["recall"], rep["F1"]], [b["precision"], b["recall"], b["f1"]], rtol=1e-12)
+        else:
+            with pytest.raises(ZeroDivisionError):
+                c.report()
+        total = total + c
+    assert total.as_list() == [sum(b[k] for b in g["batches"]) for k in keys]
+    for r in g["singles"]:
+        a, bb, c, d = print_align_space_canonical_origin(r["s1"], r["s2"], list(r["path"]))
+        assert [a, bb, c] == r["out"] and {str(k): v for k, v in d.items()} == r["d"], r
+    with pytest.raises(TypeError):
+        count_batch(["sil"], ["aa b"], ["aa b"])
+    units = [synth.phone_table_41()[i] for i in range(3, 44)]
+    rs = np.random.Generator(np.random.PCG64(5))
+    for _ in range(20):
+        n = int(rs.integers(1, 40))
+        mk = lambda: " ".join(units[int(j)] for j in rs.integers(0, 6, size=int(rs.integers(1, 25))))  # noqa: E731
+        dec, lab, can = [mk() for _ in range(n)], [mk() for _ in range(n)], [mk() for _ in range(n)]
+        assert count_batch(dec, lab, can).as_list() == oracle.eval_counts(dec, lab, can)
+

@@ -79,6 +79,18 @@ def test_g4_alignment():
             oracle.align([1] * len(e["s1"].split()), [2] * len(e["s2"].split()))
 
 
+def test_g8_evaluation_counts():
+    """SURVEY 8(f) #2: the oracle's batch evaluation against what the reference's own loops counted."""
+    g = jload("g8_eval.json")
+    keys = ("total", "TA", "FR", "FA", "TRc", "TRw", "total_wer", "num_word")
+    for b in g["batches"]:
+        assert oracle.eval_counts(b["decoded"], b["labels"], b["canonicals"]) == [b[k] for k in keys], b
+        assert oracle.eval_counts(b["decoded_nosil"], b["labels_nosil"], b["canonicals_nosil"]) == [b[k] for k in keys]
+    assert g["empty_decode_error"] == "TypeError"
+    with pytest.raises(TypeError):
+        oracle.eval_counts(["sil"], ["aa b"], ["aa b"])
+
+
 def test_g5_ctc_loss_and_grad():
     g = npz("g5_ctc.npz")
     for m in jload("g5_ctc.json"):
