@@ -137,6 +137,16 @@ int mdd_ctc_loss(const float *logp_dev, int32_t T, int32_t B, int32_t C, const i
 int mdd_align(const int32_t *a, int32_t na, const int32_t *b, int32_t nb, int32_t *dist, uint8_t *ops,
               int32_t *nops);
 
+/* ---- Kaldi-compatible log-mel filterbank + global CMVN (replaces the reference's subprocess pipe
+ * `compute-fbank-feats --config=conf/fbank.conf | apply-cmvn --norm-vars=true data/global_fbank_cmvn.txt`,
+ * AA/infer.py:567-574; options of AA/conf/fbank.conf:1-4 over Kaldi's defaults, dither 0).
+ * wav_dev: n_samples mono samples at 16 kHz on the int16 scale, as float.  out_dev: [mdd_fbank_num_frames(n), 81],
+ * column 0 = raw log energy, 1..80 = log mel energies; if both cmvn pointers are non-NULL (81 floats each, device)
+ * every column c is written as value * scale[c] + offset[c].  Parity with Kaldi is unpinned. */
+int32_t mdd_fbank_num_frames(int64_t n_samples);
+int mdd_fbank(const float *wav_dev, int64_t n_samples, const float *cmvn_scale_dev, const float *cmvn_offset_dev,
+              float *out_dev, void *stream);
+
 /* ---- evaluation counts of a batch (AA/steps/test_ctc_nosil.py:33-60,218-298), host.
  * Row x of dec / lab / can (row pitch `stride` ids) holds the decoded, annotated and canonical phoneme ids of utterance x
  * with 'sil' already removed (:196-209).  counts[8] = { phonemes in canonical, TA, FR, FA, TR correctly diagnosed,

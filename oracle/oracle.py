@@ -264,3 +264,87 @@ def eval_counts(decoded, labels, canonicals):
         out[7] += len(lab)
     return out
 
+
+# ---------------------------------------------------------------------------------------------------------------------
+# SURVEY 8(f) #1 -- the feature front-end the reference shells out to (AA/infer.py:567-574):
+#   compute-fbank-feats --config=conf/fbank.conf | apply-cmvn --norm-vars=true data/global_fbank_cmvn.txt
+# Kaldi is third-party and not in /root/reference (only unrunnable prebuilt binaries are): this restates Kaldi's
+# published algorithm (feat/feature-window.cc ExtractWindow/ProcessWindow, feat/mel-computations.cc MelBanks,
+# feat/feature-fbank.cc FbankComputer::Compute, transform/cmvn.cc ApplyCmvn) for the option set of AA/conf/fbank.conf
+# (hamming window, 80 mel bins, use-energy) with Kaldi's defaults elsewhere (16 kHz, 25 ms / 10 ms, preemphasis 0.97,
+# remove-dc-offset, snip-edges, raw-energy, power spectrum, log).  PARITY UNPINNED: no Kaldi binary or fixture output
+# exists here to check it against; dither (Kaldi default 1.0, random) is 0 unless a noise array is passed.
+FBANK = dict(samp_freq=16000.0, frame_len=400, frame_shift=160, nfft=512, num_bins=80, low_freq=20.0, preemph=0.97)
+
+
+def mel_banks(num_bins=80, nfft=512, samp_freq=16000.0, low_freq=20.0, high_freq=0.0):
+    """[(first_fft_bin, weights float32[...])] per mel bin (MelBanks::MelBanks, no VTLN, htk_mode=false)."""
+    f32 = np.float32
+    nyquist = 0.5 * samp_freq
+    if high_freq <= 0.0:
+        high_freq += nyquist
+    mel = lambda f: f32(1127.0) * np.log(f32(1.0) + f32(f) / f32(700.0), dtype=f32)  # noqa: E731
+    bin_width = f32(samp_freq / nfft)
+    mel_low, mel_high = mel(low_freq), mel(high_freq)
+    delta = f32((mel_high - mel_low) / f32(num_bins + 1))
+    mel_bins = np.array([mel(bin_width * f32(i)) for i in range(nfft // 2)], dtype=f32)
+    out = []
+    for b in range(num_bins):
+        left = f32(mel_low + f32(b) * delta)
+        center = f32(mel_low + f32(b + 1) * delta)
+        right = f32(mel_low + f32(b + 2) * delta)
+        idx = np.nonzero((mel_bins > left) & (mel_bins < right))[0]
+        w = np.where(mel_bins[idx] <= center, (mel_bins[idx] - left) / (center - left), (right - mel_bins[idx]) / (right - center)).astype(f32)
+        out.append((int(idx[0]), w))
+    return out
+
+
+def fbank(wav, dither_noise=None):
+    """wav: 1-D samples on the int16 scale (Kaldi does not normalise) -> float32 [num_frames, 81]: column 0 = log energy
+    of the raw (DC-removed) frame, columns 1..80 = log mel energies."""
+    f32 = np.float32
+    x = np.asarray(wav, dtype=f32)
+    N, S, P = FBANK["frame_len"], FBANK["frame_shift"], FBANK["nfft"]
+    nfr = 0 if len(x) < N else 1 + (len(x) - N) // S
+    banks = mel_banks()
+    window = (f32(0.54) - f32(0.46) * np.cos(2.0 * np.pi * np.arange(N) / (N - 1))).astype(f32)
+    eps = np.finfo(np.float32).eps
+    out = np.zeros((nfr, 1 + FBANK["num_bins"]), dtype=f32)
+    for f in range(nfr):
+        fr = x[f * S:f * S + N].astype(f32).copy()
+        if dither_noise is not None:
+            fr = fr + np.asarray(dither_noise[f], dtype=f32)
+        fr = fr - f32(fr.sum(dtype=f32) / f32(N))                       # remove_dc_offset
+        out[f, 0] = np.log(max(f32(np.dot(fr, fr)), eps))               # raw_energy: before preemphasis and windowing
+        pre = fr.copy()
+        pre[1:] = fr[1:] - f32(FBANK["preemph"]) * fr[:-1]
+        pre[0] = fr[0] - f32(FBANK["preemph"]) * fr[0]
+        pad = np.zeros(P, dtype=f32)
+        pad[:N] = pre * window
+        spec = np.fft.rfft(pad.astype(np.float64))
+        power = (spec.real ** 2 + spec.imag ** 2).astype(f32)           # bins 0..256; MelBanks uses 0..255
+        for b, (first, w) in enumerate(banks):
+            out[f, 1 + b] = np.log(max(f32(np.dot(w, power[first:first + len(w)])), eps))
+    return out
+
+
+def read_cmvn_stats(path):
+    """Kaldi text matrix ' [ a b ...\n c d ... ]' -> float64 [2, D+1] (row 0: sums and count, row 1: sums of squares)."""
+    txt = open(path).read().replace("[", " ").replace("]", " ")
+    rows = [r.split() for r in txt.strip().split("\n") if r.split()]
+    return np.array([[float(v) for v in r] for r in rows], dtype=np.float64)
+
+
+def apply_cmvn(feats, stats, norm_vars=True):
+    """ApplyCmvn with global stats (double arithmetic, variance floor 1e-20), float32 out."""
+    D = feats.shape[1]
+    count = stats[0, D]
+    mean = stats[0, :D] / count
+    if norm_vars:
+        var = np.maximum(stats[1, :D] / count - mean * mean, 1e-20)
+        scale = 1.0 / np.sqrt(var)
+    else:
+        scale = np.ones(D)
+    offset = -mean * scale
+    return (feats.astype(np.float64) * scale + offset).astype(np.float32)
+

@@ -342,3 +342,32 @@ def test_batch_evaluation_golden_and_oracle():
         dec, lab, can = [mk() for _ in range(n)], [mk() for _ in range(n)], [mk() for _ in range(n)]
         assert count_batch(dec, lab, can).as_list() == oracle.eval_counts(dec, lab, can)
 
+
+def test_fbank_kernel_against_oracle():
+    """the HIP filterbank (+ fused CMVN) against the numpy restatement of Kaldi's algorithm, on a word
+    from the reference's own egs/vocabulary/single (data fixture) and on noise; then through stack/skip into the
+    [T, 243] rows the model consumes.  Parity with Kaldi itself is unpinned; tolerance here is on log values."""
+    from ctc_attention_mispronunciation_amd.utils import fbank as fb
+    from ctc_attention_mispronunciation_amd.utils.data_loader import stack_features
+    wav, sr = fb.read_wav(os.path.join(GOLD, "vocabulary_single_1.wav"))
+    assert sr == 16000
+    stats = fb.read_cmvn_stats(os.path.join(GOLD, "global_fbank_cmvn.txt"))
+    want = oracle.fbank(wav)
+    got = fb.compute_fbank_feats(wav).cpu().numpy()
+    assert got.shape == want.shape == (282, 81)
+    np.testing.assert_allclose(got, want, rtol=0, atol=2e-3)
+    gotn = fb.compute_fbank_feats(wav, cmvn=fb.cmvn_scale_offset(stats)).cpu().numpy()
+    np.testing.assert_allclose(gotn, oracle.apply_cmvn(want, stats), rtol=0, atol=2e-3)
+    rs = np.random.Generator(np.random.PCG64(9))
+    for n in (399, 400, 559, 560, 16000, 48017):
+        x = (rs.standard_normal(n) * 3000).astype(np.float32)
+        g = fb.compute_fbank_feats(x).cpu().numpy()
+        w = oracle.fbank(x)
+        assert g.shape == w.shape == (max(0, 1 + (n - 400) // 160) if n >= 400 else 0, 81)
+        if len(w):
+            np.testing.assert_allclose(g, w, rtol=0, atol=2e-3)
+    stacked = stack_features(torch.from_numpy(gotn[None]).cuda()).cpu().numpy()
+    np.testing.assert_array_equal(stacked[0], oracle.stack_skip(gotn))
+    with pytest.raises(ValueError):
+        fb.compute_fbank_feats(wav, sample_rate=8000)
+

@@ -1,10 +1,12 @@
 """The CPU oracle (oracle/mdd_oracle.c) against golden vectors made by the reference's own
 Python (oracle/gen_golden.py).  CPU only.  This is what pins the oracle."""
+import os
+
 import numpy as np
 import pytest
 
 from oracle import oracle
-from tests.helpers import npz, jload, ids_to_beam_string, ids_to_greedy_string
+from tests.helpers import npz, jload, ids_to_beam_string, ids_to_greedy_string, GOLD
 from ctc_attention_mispronunciation_amd import synth
 
 ERR = {0: None, 1: "IndexError", 2: "ValueError", 3: "KeyError"}
@@ -144,3 +146,52 @@ def test_ref_port_decoders_match_goldens():
         lmf = LanguageModel(os.path.join(GOLD, f["lm"].replace("lm", "lm_synth") + ".arpa"))
         with pytest.raises({"IndexError": IndexError, "ValueError": ValueError, "KeyError": KeyError}[f["error"]]):
             ref_port.beam(g["c%d_fail_%s" % (Cn, f["name"])][:, None, :], [f["len"]], i2c, lmf, f["width"], f["alpha"])
+
+
+def test_fbank_oracle_properties_and_fixtures():
+    """SURVEY 8(f) #1 (parity with Kaldi unpinned): the numpy restatement behaves like a filterbank -- frame count of
+    snip-edges, raw log-energy column, a pure tone lands in the mel bin that contains it -- and reads the reference's
+    CMVN statistics file (committed as a data fixture)."""
+    import wave
+    rs = np.random.Generator(np.random.PCG64(3))
+    x = (rs.standard_normal(16000) * 1000).astype(np.float32)
+    F = oracle.fbank(x)
+    assert F.shape == (1 + (16000 - 400) // 160, 81) and oracle.fbank(x[:399]).shape == (0, 81)
+    fr = x[:400] - x[:400].mean(dtype=np.float32)
+    np.testing.assert_allclose(F[0, 0], np.log(np.dot(fr, fr)), rtol=1e-6)
+    banks = oracle.mel_banks()
+    assert len(banks) == 80 and banks[0][0] == 1 and banks[-1][0] + len(banks[-1][1]) == 256
+    assert all(0 < w.max() <= 1 and w.min() > 0 for _, w in banks)
+    t = np.arange(16000) / 16000.0
+    for hz in (300.0, 1000.0, 3500.0):
+        tone = oracle.fbank((8000 * np.sin(2 * np.pi * hz * t)).astype(np.float32))
+        k = int(round(hz / 31.25))
+        want = max(range(80), key=lambda b: banks[b][1][k - banks[b][0]] if 0 <= k - banks[b][0] < len(banks[b][1]) else -1)
+        assert int(np.argmax(tone[10, 1:])) == want, (hz, int(np.argmax(tone[10, 1:])), want)
+    stats = oracle.read_cmvn_stats(os.path.join(GOLD, "global_fbank_cmvn.txt"))
+    assert stats.shape == (2, 82) and stats[0, 81] > 1e6 and stats[1, 81] == 0
+    w = wave.open(os.path.join(GOLD, "vocabulary_single_1.wav"))
+    wav = np.frombuffer(w.readframes(w.getnframes()), dtype=np.int16)
+    G = oracle.apply_cmvn(oracle.fbank(wav), stats)
+    assert G.shape == (282, 81) and np.isfinite(G).all() and abs(float(G.mean())) < 3 and 0.3 < float(G.std()) < 3
+
+
+def test_fbank_host_side_wire_formats(tmp_path):
+    """Kaldi binary float-matrix ark/scp round trip and the CMVN text reader of the host mirror (no GPU involved)."""
+    from ctc_attention_mispronunciation_amd.utils import fbank as fb
+    feats = {"utt_a": np.arange(12, dtype=np.float32).reshape(3, 4), "b": np.full((2, 81), 0.5, dtype=np.float32)}
+    ark, scp = str(tmp_path / "f.ark"), str(tmp_path / "f.scp")
+    fb.write_ark_scp(ark, scp, feats)
+    back = fb.read_ark(ark)
+    assert list(back) == list(feats) and all(np.array_equal(back[k], feats[k]) for k in feats)
+    raw = open(ark, "rb").read()
+    for line in open(scp):
+        key, loc = line.split()
+        off = int(loc.rsplit(":", 1)[1])
+        assert raw[off:off + 6] == b"\0BFM \x04"[:6] and raw[off - len(key) - 1:off - 1] == key.encode()
+    stats = fb.read_cmvn_stats(os.path.join(GOLD, "global_fbank_cmvn.txt"))
+    np.testing.assert_array_equal(stats, oracle.read_cmvn_stats(os.path.join(GOLD, "global_fbank_cmvn.txt")))
+    sc, of = fb.cmvn_scale_offset(stats)
+    x = np.random.Generator(np.random.PCG64(1)).standard_normal((5, 81)).astype(np.float32)
+    np.testing.assert_allclose(x * sc + of, oracle.apply_cmvn(x, stats), rtol=1e-5, atol=1e-5)
+
