@@ -371,3 +371,33 @@ def test_fbank_kernel_against_oracle():
     with pytest.raises(ValueError):
         fb.compute_fbank_feats(wav, sample_rate=8000)
 
+
+def test_wav_to_diagnosis_end_to_end():
+    """Config (1) without any subprocess: WAV -> fbank + CMVN (HIP) -> stack/skip -> forward -> greedy -> alignment and
+    diagnosis, all through the product; posteriors checked against the oracle run on the oracle's own features."""
+    from ctc_attention_mispronunciation_amd.utils import fbank as fb
+    from ctc_attention_mispronunciation_amd.utils.ctcDecoder import GreedyDecoder
+    from ctc_attention_mispronunciation_amd.utils.data_loader import stack_features
+    from ctc_attention_mispronunciation_amd.infer_core import diagnose
+    wav, _ = fb.read_wav(os.path.join(GOLD, "vocabulary_single_1.wav"))
+    stats = fb.read_cmvn_stats(os.path.join(GOLD, "global_fbank_cmvn.txt"))
+    feats = fb.compute_fbank_feats(wav, cmvn=fb.cmvn_scale_offset(stats))
+    x = stack_features(feats[None])                                  # [1, T, 243], T even
+    assert x.shape == (1, 142, 243)
+    geom = synth.Geometry(**synth.REFERENCE)
+    sd = synth.synth_state_dict(geom, seed=11)
+    i2c = synth.phone_table_41()
+    canon = "v ow k ae b y ah l eh r iy"                             # "vocabulary"
+    c2i = {v: k for k, v in i2c.items()}
+    x1 = torch.tensor([[c2i[p] for p in canon.split()]], dtype=torch.int64).cuda()
+    logp = _hip().HipModel(geom, sd).forward(x, x1, sync_errors=True)
+    want_feats = oracle.stack_skip(oracle.apply_cmvn(oracle.fbank(wav), stats))
+    want = oracle.forward(sd, want_feats[None], x1.cpu().numpy())
+    np.testing.assert_allclose(logp.cpu().numpy(), want, rtol=0, atol=2e-3)
+    dec = GreedyDecoder(i2c, space_idx=-1, blank_index=0)
+    hyp = dec.decode(logp, [logp.shape[0]])[0]
+    assert isinstance(hyp, str)
+    if hyp.strip():
+        rep = diagnose(hyp.strip(), canon, dec)
+        assert 0 <= rep["score"] <= 100 and len(rep["path"]) >= len(canon.split())
+
