@@ -109,7 +109,6 @@ def main():
             def __init__(self, g):
                 b = g * B0
                 self.b = b
-                self.xbuf = torch.empty((b, T_raw // 2, 3 * D), device="cuda")   # fixed buffers: graphs are keyed on pointers
                 self.raw = raw[:b]
                 self.x1 = x1[:b]
                 self.lens = lens[:b]
@@ -136,8 +135,7 @@ def main():
             self.count += 1
             with torch.cuda.stream(self.s_fwd):
                 self.s_fwd.wait_event(self.ev_free[k])          # slot k's buffers no longer read by the decoder two passes ago
-                x = stack_features(bf.raw, out=bf.xbuf)
-                self.model.forward(x, bf.x1, out=bf.logp[k])
+                self.model.forward_raw(bf.raw, bf.x1, out=bf.logp[k])    # stack/skip folded into the front-end's tile load
                 if bf.gathered is not None and not args.no_gather:
                     dist.all_gather_into_tensor(bf.gathered[k].view(-1, bf.b, geom.num_class), bf.logp[k])
                 self.ev_fwd[k].record(self.s_fwd)

@@ -27,7 +27,7 @@ struct DevBuf {
 
 struct GraphKey {
     const void *x, *x1, *out;
-    int B, T, L;
+    int B, T, L, Traw;
     bool operator<(const GraphKey &o) const { return memcmp(this, &o, sizeof(GraphKey)) < 0; }
 };
 
@@ -56,6 +56,8 @@ struct mdd_model {
     int *err_flag = nullptr;
     hipStream_t cap_stream = nullptr;  // graphs are captured here (the legacy default stream cannot capture)
     int lastB = 0, lastT = 0, lastL = 0;
+    int raw_T = 0;              // > 0 while mdd_forward_raw runs the fused front-end straight on unstacked frames
+    mdd::DevBuf xstack;         // mdd_forward_raw without the fused front-end: stacked copy
     std::map<mdd::GraphKey, hipGraphExec_t> graphs;
     int W1() const { return (cfg.feat + 2 - 3) / 2 + 1; }
     int W2() const { return (W1() + 2 - 3) / 2 + 1; }
@@ -193,7 +195,7 @@ static int run_stage(mdd_model *m, int si, const float *x, int B, int T, const i
         info->name = "conv_fused";
         info->flops = 2.0 * 9 * c.channels * (double)B * Tp * m->W2() * (c.channels + 6.0);
         return launch_conv_fused(x, m->w_conv0, m->sc0, m->sh0, m->w_conv1_s, m->sc1, m->sh1, split_view(m->seq0_s, rows * m->rnn_in()),
-                                 nullptr, B, T, st);
+                                 nullptr, B, T, m->raw_T, st);
     }
     if (si == 1 && m->conv_fused()) { info->name = "conv1_in_fused"; info->launches = 0; return MDD_OK; }
     if (si == 0) { info->name = "conv0"; info->flops = 2.0 * 9 * c.channels * (double)B * T * m->W1();
@@ -338,7 +340,7 @@ extern "C" void mdd_destroy(mdd_model *m) {
     for (auto &kv : m->graphs) (void)hipGraphExecDestroy(kv.second);
     for (void *p : m->owned) (void)hipFree(p);
     DevBuf *bufs[] = {&m->y0, &m->seq0, &m->gx, &m->act[0], &m->act[1], &m->xraw, &m->hbuf, &m->cbuf, &m->embo, &m->text, &m->key, &m->S,
-                      &m->seq0_s, &m->act_s[0], &m->act_s[1], &m->x_s, &m->embo_s, &m->text_s, &m->key_s, &m->hsplit, &m->hx};
+                      &m->seq0_s, &m->act_s[0], &m->act_s[1], &m->x_s, &m->embo_s, &m->text_s, &m->key_s, &m->hsplit, &m->hx, &m->xstack};
     for (DevBuf *b : bufs) if (b->p) (void)hipFree(b->p);
     for (auto &b : m->tap_rnn) if (b.p) (void)hipFree(b.p);
     if (m->err_flag) (void)hipFree(m->err_flag);
@@ -535,7 +537,7 @@ extern "C" int mdd_forward(mdd_model *m, const float *x_dev, int32_t B, int32_t 
     if (!m->use_graph) return forward_enqueue(m, x_dev, B, T, x1_dev, L, logp_dev, st);
     GraphKey key;
     memset(&key, 0, sizeof(key));
-    key.x = x_dev; key.x1 = x1_dev; key.out = logp_dev; key.B = B; key.T = T; key.L = L;
+    key.x = x_dev; key.x1 = x1_dev; key.out = logp_dev; key.B = B; key.T = T; key.L = L; key.Traw = m->raw_T;
     auto it = m->graphs.find(key);
     if (it == m->graphs.end()) {
         if (m->graphs.size() >= 8) { for (auto &kv : m->graphs) (void)hipGraphExecDestroy(kv.second); m->graphs.clear(); }
@@ -553,6 +555,25 @@ extern "C" int mdd_forward(mdd_model *m, const float *x_dev, int32_t B, int32_t 
     }
     MDD_HIP_CHECK(hipGraphLaunch(it->second, st));
     return MDD_OK;
+}
+
+// A1 + forward in one call: raw_dev = unstacked frames [B, T_raw, feat/3].  With the fused conv front-end the stack/skip
+// is only an index map inside its x-tile load (no [B,T,243] copy at all); otherwise a stacked copy is made first.
+extern "C" int mdd_forward_raw(mdd_model *m, const float *raw_dev, int32_t B, int32_t T_raw, const int64_t *x1_dev, int32_t L,
+                               float *logp_dev, void *stream) {
+    if (!m || !raw_dev || B <= 0 || T_raw < 1) { set_error("mdd_forward_raw: bad argument"); return MDD_ERR_ARG; }
+    const int D = m->cfg.feat / 3, T = mdd_stack_len(T_raw, 2, 2);
+    if (m->cfg.feat != 3 * D) { set_error("mdd_forward_raw: feat=%d is not 3 stacked frames", m->cfg.feat); return MDD_ERR_ARG; }
+    if (m->finalized && m->conv_fused()) {
+        m->raw_T = T_raw;
+        const int rc = mdd_forward(m, raw_dev, B, T, x1_dev, L, logp_dev, stream);
+        m->raw_T = 0;
+        return rc;
+    }
+    MDD_HIP_CHECK(hipSetDevice(m->device));
+    if (int rc = ensure(m->xstack, (size_t)B * T * m->cfg.feat)) return rc;
+    if (int rc = mdd_stack_skip(raw_dev, B, T_raw, D, 2, 2, 2, m->xstack.p, stream)) return rc;
+    return mdd_forward(m, m->xstack.p, B, T, x1_dev, L, logp_dev, stream);
 }
 
 extern "C" int32_t mdd_forward_num_stages(mdd_model *m) { return m ? n_stages(m) : 0; }

@@ -177,8 +177,9 @@ __global__ __launch_bounds__(256, 2) void conv_fused_kernel(const float *__restr
                                                             const unsigned short *__restrict__ w1h, const unsigned short *__restrict__ w1l,
                                                             const float *__restrict__ sc1, const float *__restrict__ sh1,
                                                             unsigned short *__restrict__ out_hi, unsigned short *__restrict__ out_lo,
-                                                            float *__restrict__ out_f32, int B, int T) {
+                                                            float *__restrict__ out_f32, int B, int T, int Traw) {
     constexpr int F = 243, W1 = 122, W2 = 61, CH = 32, ROW = CH * W2;   // 1952
+    constexpr int D0 = F / 3;                                           // raw feature width when x holds unstacked frames
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float *xs = reinterpret_cast<float *>(smem);                                   // [5][CF_XLD]
     unsigned char *yh = smem + 5 * CF_XLD * 4, *yl = yh + CF_YPLANE;               // conv0 tile, hi / lo
@@ -220,7 +221,13 @@ __global__ __launch_bounds__(256, 2) void conv_fused_kernel(const float *__restr
         // ---- x rows 2tp-2 .. 2tp+2, columns -1 .. 243 (zero outside)
         for (int i = tid; i < 5 * CF_XLD; i += 256) {
             const int r = i / CF_XLD, c = i - r * CF_XLD - 1, ti = 2 * tp - 2 + r;
-            xs[i] = (ti >= 0 && ti < T && c >= 0 && c < F) ? x[((size_t)b * T + ti) * F + c] : 0.f;
+            if (Traw == 0) {
+                xs[i] = (ti >= 0 && ti < T && c >= 0 && c < F) ? x[((size_t)b * T + ti) * F + c] : 0.f;
+            } else {   // x = raw frames [B, Traw, 81]: stacked frame ti = raw frames 2ti, 2ti+1, 2ti+2 (last frame repeated past the
+                       // end, tools.py:207-220), frames 0, 2, 4, .. kept (:222-227), zero rows up to an even count (data_loader.py:140-142)
+                const int j = c / D0, fr = min(2 * ti + j, Traw - 1);
+                xs[i] = (ti >= 0 && 2 * ti < Traw && c >= 0 && c < F) ? x[((size_t)b * Traw + fr) * D0 + (c - j * D0)] : 0.f;
+            }
         }
         __syncthreads();
         // ---- conv0 on the matrix cores: D[ch, pos] = W0[ch, k] . P[k, pos], k = 9 taps padded to 16 (one MFMA k-step),
@@ -323,11 +330,11 @@ __global__ __launch_bounds__(256, 2) void conv_fused_kernel(const float *__restr
 size_t conv_fused_smem() { return 5 * CF_XLD * 4 + 2 * (size_t)CF_YPLANE + 2048 * 4 + 2 * 1952 * 2; }
 
 int launch_conv_fused(const float *x, const float *w0, const float *sc0, const float *sh0, SplitPtr w1, const float *sc1,
-                      const float *sh1, SplitPtr out, float *out_f32, int B, int T, hipStream_t st) {
+                      const float *sh1, SplitPtr out, float *out_f32, int B, int T, int Traw, hipStream_t st) {
     const int rows = (T / 2) * B;
     int grid = rows < 2048 ? rows : 2048;
     hipLaunchKernelGGL(conv_fused_kernel, dim3(grid), dim3(256), conv_fused_smem(), st, x, w0, sc0, sh0, w1.hi, w1.lo, sc1, sh1,
-                       out.hi, out.lo, out_f32, B, T);
+                       out.hi, out.lo, out_f32, B, T, Traw);
     MDD_LAUNCH_CHECK();
     return MDD_OK;
 }

@@ -52,7 +52,7 @@ int launch_conv1(const float *y0, const float *w_t, const float *scale, const fl
 // conv0 -> conv1 fused on the bf16 matrix cores (feat 243, 32 channels): x [B,T,243] -> split-bf16 rows [T/2*B, 1952]
 // (w1: conv1 weights as [co][kh][kw][ci] hi/lo planes).  out_f32 optional (taps).
 int launch_conv_fused(const float *x, const float *w0, const float *sc0, const float *sh0, SplitPtr w1, const float *sc1,
-                      const float *sh1, SplitPtr out, float *out_f32, int B, int T, hipStream_t st);
+                      const float *sh1, SplitPtr out, float *out_f32, int B, int T, int Traw, hipStream_t st);
 int init_conv_attributes();
 
 struct LstmStepArgs {

@@ -54,6 +54,24 @@ class HipModel(object):
                 raise IndexError(_lib.lib().mdd_last_error().decode())
         return out
 
+    def forward_raw(self, raw, x1, out=None, sync_errors=False):
+        """raw [B,T_raw,F/3] f32 cuda (unstacked frames), x1 [B,L] i64 cuda -> logp, exactly as
+        forward(stack_features(raw), x1): the stack/skip of data_loader.py:138-142 is applied on the fly."""
+        assert raw.is_cuda and x1.is_cuda and raw.dtype == torch.float32 and x1.dtype == torch.int64
+        raw, x1 = raw.contiguous(), x1.contiguous()
+        B, T_raw, D = raw.shape
+        assert 3 * D == self.geom.feat
+        T = _lib.lib().mdd_stack_len(T_raw, 2, 2)
+        if out is None:
+            out = torch.empty((T // 2, B, self.geom.num_class), dtype=torch.float32, device=raw.device)
+        st = _lib.current_stream_ptr()
+        _lib.check(_lib.lib().mdd_forward_raw(self.handle, C.c_void_p(raw.data_ptr()), B, T_raw, C.c_void_p(x1.data_ptr()),
+                                              x1.shape[1], C.c_void_p(out.data_ptr()), st))
+        if sync_errors:
+            if _lib.lib().mdd_sync(self.handle, st) != 0:
+                raise IndexError(_lib.lib().mdd_last_error().decode())
+        return out
+
     def profile(self, x, x1):
         """Per-stage (name, ms, launches, flops) of one forward replayed stage by stage between HIP events."""
         B, T, _ = x.shape

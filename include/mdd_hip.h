@@ -90,6 +90,12 @@ int32_t mdd_len_frames(int32_t len, int32_t maxlen, int32_t t_out);
  * (the reference raises IndexError) and are reported by the next mdd_sync(). */
 int mdd_forward(mdd_model *m, const float *x_dev, int32_t B, int32_t T, const int64_t *x1_dev, int32_t L,
                 float *logp_dev, void *stream);
+/* ---- A1 + A2..A7 in one call: raw_dev holds the unstacked frames [B, T_raw, feat/3] (make_context(.,0,2) + skip_feat(.,2)
+ * + even padding are applied on the fly: AA/utils/tools.py:207-227, AA/utils/data_loader.py:138-142); logp_dev is
+ * [mdd_stack_len(T_raw,2,2)/2, B, C].  Same results, bit for bit, as mdd_stack_skip followed by mdd_forward. */
+int mdd_forward_raw(mdd_model *m, const float *raw_dev, int32_t B, int32_t T_raw, const int64_t *x1_dev, int32_t L,
+                    float *logp_dev, void *stream);
+
 /* The same forward replayed stage by stage between HIP events on `stream` (measurement aid for bench.py:
  * per-stage wall time, kernel launches and algorithmic flops).  names: comma-separated stage names. */
 int32_t mdd_forward_num_stages(mdd_model *m);
