@@ -215,20 +215,36 @@ __global__ __launch_bounds__(256, 2) void conv_fused_kernel(const float *__restr
         reinterpret_cast<unsigned int *>((rem < CF_COLB / 4 ? yh : yl) + r * CF_NCOL * CF_COLB)[rem % (CF_COLB / 4)] = 0u;
     }
 
+    // x rows 2tp-2 .. 2tp+2, columns -1 .. 243 (zero outside) of one output row: 5*248 elements, 5 per thread.  The next
+    // row's elements are requested before this row's arithmetic starts and parked in registers (a row is otherwise a
+    // chain global load -> LDS -> conv0 -> conv1 with the ~1 us load latency exposed every time).
+    constexpr int XPT = (5 * CF_XLD + 255) / 256;
+    auto load_x = [&](int rowid, float (&dst)[XPT]) {
+        const int tp = rowid / B, b = rowid - tp * B;
+#pragma unroll
+        for (int k = 0; k < XPT; k++) {
+            const int i = tid + 256 * k, r = i / CF_XLD, c = i - r * CF_XLD - 1, ti = 2 * tp - 2 + r;
+            float v = 0.f;
+            if (i < 5 * CF_XLD) {
+                if (Traw == 0) {
+                    if (ti >= 0 && ti < T && c >= 0 && c < F) v = x[((size_t)b * T + ti) * F + c];
+                } else {   // x = raw frames [B, Traw, 81]: stacked frame ti = raw frames 2ti, 2ti+1, 2ti+2 (last frame repeated past the
+                           // end, tools.py:207-220), frames 0, 2, 4, .. kept (:222-227), zero rows up to an even count (data_loader.py:140-142)
+                    const int j = c / D0, fr = min(2 * ti + j, Traw - 1);
+                    if (ti >= 0 && 2 * ti < Traw && c >= 0 && c < F) v = x[((size_t)b * Traw + fr) * D0 + (c - j * D0)];
+                }
+            }
+            dst[k] = v;
+        }
+    };
+    float xnext[XPT];
+    if ((int)blockIdx.x < Tp * B) load_x(blockIdx.x, xnext);
     for (int rowid = blockIdx.x; rowid < Tp * B; rowid += gridDim.x) {
         const int tp = rowid / B, b = rowid - tp * B;
         __syncthreads();                                                           // previous row's LDS fully consumed
-        // ---- x rows 2tp-2 .. 2tp+2, columns -1 .. 243 (zero outside)
-        for (int i = tid; i < 5 * CF_XLD; i += 256) {
-            const int r = i / CF_XLD, c = i - r * CF_XLD - 1, ti = 2 * tp - 2 + r;
-            if (Traw == 0) {
-                xs[i] = (ti >= 0 && ti < T && c >= 0 && c < F) ? x[((size_t)b * T + ti) * F + c] : 0.f;
-            } else {   // x = raw frames [B, Traw, 81]: stacked frame ti = raw frames 2ti, 2ti+1, 2ti+2 (last frame repeated past the
-                       // end, tools.py:207-220), frames 0, 2, 4, .. kept (:222-227), zero rows up to an even count (data_loader.py:140-142)
-                const int j = c / D0, fr = min(2 * ti + j, Traw - 1);
-                xs[i] = (ti >= 0 && 2 * ti < Traw && c >= 0 && c < F) ? x[((size_t)b * Traw + fr) * D0 + (c - j * D0)] : 0.f;
-            }
-        }
+#pragma unroll
+        for (int k = 0; k < XPT; k++) if (tid + 256 * k < 5 * CF_XLD) xs[tid + 256 * k] = xnext[k];
+        if (rowid + (int)gridDim.x < Tp * B) load_x(rowid + gridDim.x, xnext);
         __syncthreads();
         // ---- conv0 on the matrix cores: D[ch, pos] = W0[ch, k] . P[k, pos], k = 9 taps padded to 16 (one MFMA k-step),
         // bf16x3.  A = weights (resident fragments), B = the 3x3 patch of each of the 3*122 = 366 positions (12 tiles of
