@@ -35,8 +35,8 @@ PEAK_HBM_GBS = 8000.0
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=128)
-    ap.add_argument("--warmup", type=int, default=16)
+    ap.add_argument("--steps", type=int, default=256)
+    ap.add_argument("--warmup", type=int, default=32)
     ap.add_argument("--workload", default="joint64", choices=["joint64", "greedy32"])
     ap.add_argument("--hidden", type=int, default=384)
     ap.add_argument("--lanes", type=int, default=1, help="independent stream pipelines per GPU")
