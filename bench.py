@@ -218,8 +218,8 @@ def main():
             if name.startswith("gemm"):
                 if not x3:
                     return "gemm_nt_f32_kernel"
-                # launch_gemm_bf16x3's dispatch: fp32-output, unbatched, >= 1024 x 512 problems take the 256x256 LDS-DMA tile
-                return "gemm_bf16x3_glds256_kernel" if name.startswith(("gemm_ih", "gemm_text")) and B * min(Tp, L) >= 1024 else "gemm_bf16x3_glds_kernel"
+                # launch_gemm_bf16x3's dispatch: fp32-output, unbatched, >= 1024 x 512 problems take the 256x256 8-phase kernel
+                return "gemm_bf16x3_ph8_kernel" if name.startswith(("gemm_ih", "gemm_text")) and B * min(Tp, L) >= 1024 else "gemm_bf16x3_glds_kernel"
             return {"conv_fused": "conv_fused_kernel", "attn_tail": "attn_tail_mfma_kernel", "embed": "embed_kernel"}.get(name, name)
         groups = {}
         for name, ms, launches, flops in stages:
@@ -228,7 +228,7 @@ def main():
         cand = {k: v for k, v in groups.items() if k.startswith(("lstm_", "gemm_"))}
         kern = max(cand, key=lambda k: cand[k][0])
         ms, launches, flops = cand[kern]
-        bf16_kernel = kern in ("gemm_bf16x3_glds256_kernel", "gemm_bf16x3_glds_kernel", "lstm_layer_granule_kernel", "lstm_layer_persistent_kernel")
+        bf16_kernel = kern in ("gemm_bf16x3_ph8_kernel", "gemm_bf16x3_glds256_kernel", "gemm_bf16x3_glds_kernel", "lstm_layer_granule_kernel", "lstm_layer_persistent_kernel")
         peak = PEAK_BF16_MATRIX_TFLOPS if bf16_kernel else PEAK_F32_MATRIX_TFLOPS
         achieved = flops / (ms * 1e-3) / 1e12
         traffic = None

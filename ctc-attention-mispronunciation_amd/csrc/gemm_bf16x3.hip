@@ -439,9 +439,139 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16x3_glds256_kernel(const unsig
     }
 }
 
+// ---- 256x256 tile, eight barrier-delimited phases per K-tile, two wave groups one barrier apart.
+// Same LDS image and the same per-element arithmetic as gemm_bf16x3_glds256_kernel<1> (identical bits); what changes is
+// who waits for what.  The K-tile's operands are four half-tiles (A rows 0..127 / 128..255, W rows 0..127 / 128..255;
+// hi + lo planes, 16 KB = 16 LDS-DMA pieces = 2 per wave) and a wave's share of C is four 64x32 quadrants (A half a,
+// W half b) taken in the order (0,0) (0,1) (1,1) (1,0).  A quadrant is a load phase L (fragment reads for it, the two
+// DMA pieces of one half-tile of the NEXT K-tile, a counted s_waitcnt vmcnt(4) that retires the half-tile the next L
+// will read while the two issued after it stay in flight) and an MFMA phase M (24 MFMAs), each ended by a raw
+// s_barrier.  Waves 4..7 (the other wave of every SIMD) run one barrier behind waves 0..3, so one group's M always
+// overlaps the other group's L: the matrix pipe no longer idles while both waves of a SIMD read fragments and wait.
+// Hazards: a half-tile issued in phase p is waited for at the end of L(p+2) by every wave, read in L(p+3) -- for the
+// late group that is after one more barrier than the early group's wait, as the stagger requires -- and its buffer is
+// refilled eight phases later.
+__global__ __launch_bounds__(512, 2) void gemm_bf16x3_ph8_kernel(const unsigned short *__restrict__ Ah, const unsigned short *__restrict__ Al,
+                                                                 const unsigned short *__restrict__ Wh, const unsigned short *__restrict__ Wl,
+                                                                 const float *__restrict__ bias, float *__restrict__ C, int M, int N, int K,
+                                                                 int lda, int ldw, int ldc, int tiles_n) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char glds_smem[];   // [2 stages][Ah|Al|Wh|Wl][256 rows x 64 B] = 128 KB
+    constexpr int PL = 256 * XROW;                                              // 16 KB per plane
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2, wr = (wave >> 1) & 1, wc = (wave & 1) + 2 * grp;   // SIMD partners w, w+4 sit in different groups
+    int nwg = gridDim.x, bid = blockIdx.x;
+    int q = nwg >> 3, rem = nwg & 7, xcd = bid & 7;
+    int swz = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + (bid >> 3);
+    const int tm = swz / tiles_n, tn = swz % tiles_n;
+    const int m0 = tm * 256, n0 = tn * 256;
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    f32x4 acc[2][2][4][2];                                          // [A half][W half][row tile][col tile]
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int b = 0; b < 2; b++)
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+#pragma unroll
+                for (int j = 0; j < 2; j++) acc[a][b][i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // half-tile ht of the K-tile at k0 -> stage: 0 = A half 0, 1 = W half 0, 2 = W half 1, 3 = A half 1; this wave's 2 pieces
+    auto issue = [&](int ht, int k0, unsigned char *stage) {
+        const bool isA = ht == 0 || ht == 3;
+        const int half = (ht >= 2) ? 1 : 0, g = half * 8 + wave;     // 16-row group inside the plane
+        const int row = g * 16 + (lane >> 2), cp = lane & 3, c = cp ^ ((row >> 2) & 3);
+        const int ld = isA ? lda : ldw, rtot = isA ? M : N, r0 = isA ? m0 : n0;
+        const size_t off = (size_t)min(r0 + row, rtot - 1) * ld + k0 + c * 8;
+        __builtin_amdgcn_global_load_lds((isA ? Ah : Wh) + off, (lds_void *)(stage + (isA ? 0 : 2) * PL + g * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((isA ? Al : Wl) + off, (lds_void *)(stage + (isA ? 1 : 3) * PL + g * 1024), 16, 0, 0);
+    };
+    const int nk = K / XBK;
+    const int l16 = lane & 15, kq16 = (lane >> 4) * 16;
+#pragma unroll
+    for (int ht = 0; ht < 4; ht++) issue(ht, 0, glds_smem);
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                 // A0, W0 of K-tile 0
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (grp == 1) asm volatile("s_barrier" ::: "memory");            // from here on one barrier behind group 0
+    bf16x8 fah[4], fal[4], fwh[2][2], fwl[2][2];                     // A fragments of the current half; W fragments of both halves
+#define PH8_END_L() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); __builtin_amdgcn_s_setprio(1)
+#define PH8_END_M() __builtin_amdgcn_s_setprio(0); asm volatile("s_barrier" ::: "memory")
+#define PH8_LOAD_A(a_) _Pragma("unroll") for (int i = 0; i < 4; i++) { \
+            fah[i] = x3_frag(st, (a_) * 128 + wr * 64 + i * 16 + l16, kq16); fal[i] = x3_frag(st + PL, (a_) * 128 + wr * 64 + i * 16 + l16, kq16); }
+#define PH8_LOAD_W(b_) _Pragma("unroll") for (int j = 0; j < 2; j++) { \
+            fwh[b_][j] = x3_frag(st + 2 * PL, (b_) * 128 + wc * 32 + j * 16 + l16, kq16); fwl[b_][j] = x3_frag(st + 3 * PL, (b_) * 128 + wc * 32 + j * 16 + l16, kq16); }
+#define PH8_MFMA(a_, b_) _Pragma("unroll") for (int i = 0; i < 4; i++) { \
+            _Pragma("unroll") for (int j = 0; j < 2; j++) acc[a_][b_][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fah[i], fwl[b_][j], acc[a_][b_][i][j], 0, 0, 0); \
+            _Pragma("unroll") for (int j = 0; j < 2; j++) acc[a_][b_][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fal[i], fwh[b_][j], acc[a_][b_][i][j], 0, 0, 0); \
+            _Pragma("unroll") for (int j = 0; j < 2; j++) acc[a_][b_][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fah[i], fwh[b_][j], acc[a_][b_][i][j], 0, 0, 0); }
+    for (int kt = 0; kt < nk; kt++) {
+        const unsigned char *st = glds_smem + (kt & 1) * 4 * PL;
+        unsigned char *nst = glds_smem + ((kt & 1) ^ 1) * 4 * PL;
+        const bool more = kt + 1 < nk;
+        const int nk0 = (kt + 1) * XBK;
+        // ---- quadrant (0,0)
+        PH8_LOAD_A(0) PH8_LOAD_W(0)
+        if (more) issue(0, nk0, nst);
+        if (more) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");   // W1 of this K-tile
+        __builtin_amdgcn_sched_barrier(0);
+        PH8_END_L();
+        PH8_MFMA(0, 0)
+        __builtin_amdgcn_sched_barrier(0);
+        PH8_END_M();
+        // ---- quadrant (0,1)
+        PH8_LOAD_W(1)
+        if (more) issue(1, nk0, nst);
+        if (more) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // A1 of this K-tile
+        __builtin_amdgcn_sched_barrier(0);
+        PH8_END_L();
+        PH8_MFMA(0, 1)
+        __builtin_amdgcn_sched_barrier(0);
+        PH8_END_M();
+        // ---- quadrant (1,1)
+        PH8_LOAD_A(1)
+        if (more) issue(2, nk0, nst);
+        __builtin_amdgcn_sched_barrier(0);
+        PH8_END_L();
+        PH8_MFMA(1, 1)
+        __builtin_amdgcn_sched_barrier(0);
+        PH8_END_M();
+        // ---- quadrant (1,0): its fragments are already in registers
+        if (more) { issue(3, nk0, nst); asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }   // A0, W0 of the next K-tile
+        __builtin_amdgcn_sched_barrier(0);
+        PH8_END_L();
+        PH8_MFMA(1, 0)
+        __builtin_amdgcn_sched_barrier(0);
+        PH8_END_M();
+    }
+#undef PH8_END_L
+#undef PH8_END_M
+#undef PH8_LOAD_A
+#undef PH8_LOAD_W
+#undef PH8_MFMA
+    if (grp == 0) asm volatile("s_barrier" ::: "memory");            // pairs with group 1's last barrier
+    // 16x16 C/D: col = lane&15, row = 4*(lane>>4) + r
+    const int q4 = (lane >> 4) * 4;
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int b = 0; b < 2; b++)
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+#pragma unroll
+                for (int j = 0; j < 2; j++) {
+                    const int col = n0 + b * 128 + wc * 32 + j * 16 + l16;
+                    if (col >= N) continue;
+                    const float bv = bias ? bias[col] : 0.f;
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const int row = m0 + a * 128 + wr * 64 + i * 16 + q4 + r;
+                        if (row < M) C[(size_t)row * ldc + col] = acc[a][b][i][j][r] + bv;
+                    }
+                }
+}
+
 int init_gemm_attributes() {
     MDD_HIP_CHECK(hipFuncSetAttribute((const void *)gemm_bf16x3_glds256_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 4 * 256 * XROW));
     MDD_HIP_CHECK(hipFuncSetAttribute((const void *)gemm_bf16x3_glds256_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 4 * 256 * XROW));
+    MDD_HIP_CHECK(hipFuncSetAttribute((const void *)gemm_bf16x3_ph8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 4 * 256 * XROW));
     return MDD_OK;
 }
 
@@ -455,7 +585,10 @@ int launch_gemm_bf16x3(const SplitPtr &A, const SplitPtr &W, const float *bias, 
     if (mode == 2 && !Csplit && batch == 1 && M >= 1024 && N >= 512) {   // large projection: LDS-DMA, 256x256 tiles
         const int tn = (N + 255) / 256;
         static const int shape = getenv("MDD_MFMA32") ? 0 : 1;   // 16x16x32 holds a higher clock on real data: 2.00 vs 2.32 ms in the model
-        if (shape) hipLaunchKernelGGL(gemm_bf16x3_glds256_kernel<1>, dim3(((M + 255) / 256) * tn), dim3(512), 2 * 4 * 256 * XROW, st, A.hi, A.lo, W.hi, W.lo, bias,
+        static const bool ph8 = !(getenv("MDD_GEMM") && !strcmp(getenv("MDD_GEMM"), "glds256")) && !getenv("MDD_MFMA32");
+        if (ph8) hipLaunchKernelGGL(gemm_bf16x3_ph8_kernel, dim3(((M + 255) / 256) * tn), dim3(512), 2 * 4 * 256 * XROW, st, A.hi, A.lo, W.hi, W.lo, bias,
+                           C, M, N, K, lda, ldw, ldc, tn);
+        else if (shape) hipLaunchKernelGGL(gemm_bf16x3_glds256_kernel<1>, dim3(((M + 255) / 256) * tn), dim3(512), 2 * 4 * 256 * XROW, st, A.hi, A.lo, W.hi, W.lo, bias,
                            C, M, N, K, lda, ldw, ldc, tn);
         else hipLaunchKernelGGL(gemm_bf16x3_glds256_kernel<0>, dim3(((M + 255) / 256) * tn), dim3(512), 2 * 4 * 256 * XROW, st, A.hi, A.lo, W.hi, W.lo, bias,
                            C, M, N, K, lda, ldw, ldc, tn);
@@ -533,6 +666,53 @@ extern "C" int mdd_diag_gemm(int M, int N, int K, int abl, int iters, float *ms_
     hipFree(A); hipFree(W); hipFree(C); hipEventDestroy(e0); hipEventDestroy(e1);
     return MDD_OK;
 }
+namespace mdd {
+__global__ void diag_fill_kernel(unsigned short *p, size_t n, unsigned seed) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        unsigned h = (unsigned)i * 2654435761u + seed; h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+        p[i] = (unsigned short)(0x3c00u + (h & 0x3ffu) + ((h >> 10) & 1u) * 0x8000u);   // bf16 of magnitude 0.0078..0.031, random sign
+    }
+}
+__global__ void diag_diff_kernel(const unsigned *a, const unsigned *b, size_t n, unsigned *count) {
+    unsigned c = 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) c += a[i] != b[i];
+    if (c) atomicAdd(count, c);
+}
+}  // namespace mdd
+
+// Race screen for the 8-phase kernel (not part of the ABI; tests/test_gpu_parity.py): the same pseudo-random split
+// operands through the single-barrier kernel once and through the 8-phase kernel `reps` times; returns the number of
+// C words that ever differed (both kernels perform the same arithmetic per element, so it must be 0).
+extern "C" int mdd_diag_gemm_ph8(int M, int N, int K, int reps, unsigned seed, unsigned *mismatches_out) {
+    using namespace mdd;
+    if (M <= 0 || N <= 0 || K < XBK || K % XBK || !mismatches_out) { set_error("mdd_diag_gemm_ph8: bad shape"); return MDD_ERR_ARG; }
+    static bool at = false; if (!at) { if (int rc = init_gemm_attributes()) return rc; at = true; }
+    unsigned short *A = nullptr, *W = nullptr; float *C1 = nullptr, *C2 = nullptr; unsigned *cnt = nullptr;
+    MDD_HIP_CHECK(hipMalloc((void **)&A, (size_t)2 * M * K * 2));
+    MDD_HIP_CHECK(hipMalloc((void **)&W, (size_t)2 * N * K * 2));
+    MDD_HIP_CHECK(hipMalloc((void **)&C1, (size_t)M * N * 4));
+    MDD_HIP_CHECK(hipMalloc((void **)&C2, (size_t)M * N * 4));
+    MDD_HIP_CHECK(hipMalloc((void **)&cnt, 4));
+    MDD_HIP_CHECK(hipMemset(cnt, 0, 4));
+    hipLaunchKernelGGL(diag_fill_kernel, dim3(1024), dim3(256), 0, nullptr, A, (size_t)2 * M * K, seed);
+    hipLaunchKernelGGL(diag_fill_kernel, dim3(1024), dim3(256), 0, nullptr, W, (size_t)2 * N * K, seed * 7919u + 13u);
+    const int tn = (N + 255) / 256;
+    const dim3 grid(((M + 255) / 256) * tn), block(512);
+    hipLaunchKernelGGL(gemm_bf16x3_glds256_kernel<1>, grid, block, 2 * 4 * 256 * XROW, nullptr, A, A + (size_t)M * K, W, W + (size_t)N * K,
+                       (const float *)nullptr, C1, M, N, K, K, K, N, tn);
+    for (int r = 0; r < reps; r++) {
+        MDD_HIP_CHECK(hipMemsetAsync(C2, 0xff, (size_t)M * N * 4, nullptr));
+        hipLaunchKernelGGL(gemm_bf16x3_ph8_kernel, grid, block, 2 * 4 * 256 * XROW, nullptr, A, A + (size_t)M * K, W, W + (size_t)N * K,
+                           (const float *)nullptr, C2, M, N, K, K, K, N, tn);
+        hipLaunchKernelGGL(diag_diff_kernel, dim3(1024), dim3(256), 0, nullptr, reinterpret_cast<const unsigned *>(C1),
+                           reinterpret_cast<const unsigned *>(C2), (size_t)M * N, cnt);
+    }
+    MDD_HIP_CHECK(hipMemcpy(mismatches_out, cnt, 4, hipMemcpyDeviceToHost));
+    hipFree(A); hipFree(W); hipFree(C1); hipFree(C2); hipFree(cnt);
+    MDD_LAUNCH_CHECK();
+    return MDD_OK;
+}
+
 namespace mdd {
 
 // fp32 [n] -> hi/lo planes (used for weights at load time and by the tap / test helpers)

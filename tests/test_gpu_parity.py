@@ -419,3 +419,21 @@ def test_forward_raw_equals_stack_then_forward(T_raw, precision):
     got = m.forward_raw(raw, x1, sync_errors=True).cpu().numpy()
     np.testing.assert_array_equal(got, want)
 
+
+@pytest.mark.parametrize("M,N,K", [(256, 512, 32), (1024, 512, 64), (4096, 3072, 768), (4100, 3072, 1952), (16000, 3072, 768), (1300, 800, 96)])
+def test_gemm_8phase_race_screen(M, N, K):
+    """The 8-phase projection GEMM (two wave groups a barrier apart, LDS-DMA in flight across raw barriers, counted
+    vmcnt) performs the same arithmetic per C element as the single-barrier kernel: pseudo-random operands through
+    both, the 8-phase one 12 times per shape, every C word compared -- including one-K-tile, two-K-tile, ragged-M and
+    ragged-N shapes.  A synchronisation slip would show as a mismatch in some repetition."""
+    import ctypes as C
+    from ctypes import c_int, c_uint
+    from ctc_attention_mispronunciation_amd import _lib
+    L = _lib.lib()
+    torch.zeros(1).cuda()
+    bad = c_uint(12345)
+    for seed in (1, 2):
+        rc = L.mdd_diag_gemm_ph8(c_int(M), c_int(N), c_int(K), c_int(12), c_uint(seed), C.byref(bad))
+        assert rc == 0, L.mdd_last_error().decode()
+        assert bad.value == 0, (M, N, K, seed, bad.value)
+
