@@ -537,21 +537,40 @@ __device__ __forceinline__ void wait_vmcnt(int n) {   // s_waitcnt vmcnt(n) for 
     }
 }
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+// One LDS-DMA instruction (64 lanes x 16 bytes -> 1 KB lane-linear at the wave-uniform LDS address l), written as
+// inline assembly on purpose: the compiler's wait-count pass treats the builtin form as an LDS write still in flight
+// and puts s_waitcnt vmcnt(0) in front of the next LDS read it can relate to it -- here the cell update's slab read and
+// the staged sweep's read-back -- which also waits for every store issued in between (the write-through publish alone
+// takes ~1 us to acknowledge) and for the sweep request the kernel wants in flight during the cell update.  All waits
+// on these transfers are the explicit counted ones below.
+// Same, with the global address as a wave-uniform base (SGPR pair) plus a 32-bit per-lane byte offset and the LDS
+// address already scalar: no 64-bit vector address arithmetic per piece.
+template <bool SC1>
+__device__ __forceinline__ void lds_dma16_s(const void *sbase, unsigned voff, unsigned la) {
+    if (SC1) asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 sc1" :: "v"(voff), "s"(sbase), "s"(la) : "memory", "m0");
+    else asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(voff), "s"(sbase), "s"(la) : "memory", "m0");
+}
+template <bool SC1>
+__device__ __forceinline__ void lds_dma16(const void *g, void *l) {
+    const unsigned la = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)(lds_void_t *)l);
+    if (SC1) asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off sc1" :: "v"(g), "s"(la) : "memory", "m0");
+    else asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(g), "s"(la) : "memory", "m0");
+}
 
 template <int H, int NBT, int RTW>
 __global__ __launch_bounds__(256, 1) void lstm_layer_granule_kernel(PersistArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int NTH = 256, KS = H / 32, ROWB = H * 2 + 16, RM = 4 * H / 8;
+    constexpr int NTH = 256, KS = H / 32, RM = 4 * H / 8;
     constexpr int PF = NBT == 1 ? 0 : (NBT == 2 ? 1 : 2);          // where the next phase's sweep is requested (see above)
     static_assert(RM == 4 * RTW * 16, "4 waves x RTW row tiles must cover the workgroup's gate rows");
-    unsigned char *Ph = smem, *Pl = smem + (size_t)16 * ROWB;      // the active tile's h panel, hi / lo planes
     constexpr int UW = RM / 4;                                      // units this workgroup owns (a 2*UW-byte run per output row and plane)
-    unsigned short *Oh = reinterpret_cast<unsigned short *>(smem + (size_t)2 * 16 * ROWB), *Ol = Oh + 16 * UW;   // step outputs, [row][unit]
+    unsigned short *Oh = reinterpret_cast<unsigned short *>(smem), *Ol = Oh + 16 * UW;   // step outputs, [row][unit]
     float *Of = reinterpret_cast<float *>(Ol + 16 * UW);
-    unsigned int *Og = reinterpret_cast<unsigned int *>(Of + 16 * UW);   // this step's h as tagged words, [row][unit]
+    unsigned int *Og = reinterpret_cast<unsigned int *>(Of + 16 * UW);   // this step's h as tagged words, [unit chunk][row][4 units]: the publish order
     float *Gx = reinterpret_cast<float *>(Og + 16 * UW);            // [NBT][2 step parities][16 rows][UW units][4 gates] gate pre-activations (LDS-DMA)
     constexpr int GXT = 16 * UW * 4;                                // floats per tile slab
-    unsigned char *Rw = reinterpret_cast<unsigned char *>(Gx + NBT * 2 * GXT);   // PF > 0: raw granules of the sweep requested ahead (LDS-DMA)
+    constexpr int PANB = 16 * H * 4;                                // bytes of one tile panel
+    unsigned char *Rw = reinterpret_cast<unsigned char *>(Gx + NBT * 2 * GXT);   // [2][PANB] tile panels as they travel (LDS-DMA), alternating per phase
     static_assert(UW % 8 == 0 && (16 * UW) % NTH == 0, "output rows are whole 16-byte chunks; the gx slab is whole 1 KB wave loads");
     __shared__ int s_fail;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -563,14 +582,13 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_granule_kernel(PersistArgs 
     if (tid == 0) s_fail = 0;
 
     bf16x8 ah[RTW][KS], al[RTW][KS];
-    int unit[RTW];
     float osc[RTW], osh[RTW];
 #pragma unroll
     for (int rt = 0; rt < RTW; rt++) {
         const int r0 = member * RM + (wave * RTW + rt) * 16;
-        unit[rt] = (r0 >> 2) + kq;
-        osc[rt] = a.oscale ? a.oscale[d * H + unit[rt]] : 1.f;
-        osh[rt] = a.oscale ? a.oshift[d * H + unit[rt]] : 0.f;
+        const int unit = (r0 >> 2) + kq;
+        osc[rt] = a.oscale ? a.oscale[d * H + unit] : 1.f;
+        osh[rt] = a.oscale ? a.oshift[d * H + unit] : 0.f;
         const unsigned short *wh = a.whh.hi + ((size_t)d * 4 * H + r0 + li) * H + kq * 8;
         const unsigned short *wl = a.whh.lo + ((size_t)d * 4 * H + r0 + li) * H + kq * 8;
 #pragma unroll
@@ -584,19 +602,14 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_granule_kernel(PersistArgs 
     for (int rt = 0; rt < RTW; rt++)
 #pragma unroll
         for (int bt = 0; bt < NBT; bt++) cst[rt][bt] = 0.f;
-    constexpr size_t tgran = (size_t)16 * H / 2;                   // granules per tile panel: [row][unit pair]
+    // A tile panel in the exchange buffer and in LDS: 16-byte chunks {4 tagged words = 4 consecutive units of one row},
+    // chunk index = (unit / 4) * 16 + row.  A workgroup's share (its UW units x 16 rows) is then ONE contiguous run, the
+    // sweep is a linear copy, and the MFMA operand of lane (row li, k-quarter kq) at k-step ks is the two chunks
+    // (ks * 8 + kq * 2 + {0, 1}) * 16 + li: the 16 lanes of a quarter read 256 contiguous bytes (no bank conflicts).
+    constexpr size_t tgran = (size_t)16 * H / 2;                   // 8-byte granules per tile panel
     const size_t pgran = NBT * tgran;                              // granules per (parity, team)
-    // rows past the team's real batch rows are never published nor swept: their panel rows stay zero
-    constexpr int NLD = 16 * H / 4 / NTH;                          // 16-byte chunks (2 granules = 4 units) per thread and tile
-    static_assert(16 * H / 4 % NTH == 0 && H % 4 == 0, "panel must be whole passes of the workgroup");
-    int prow[NLD], pdst[NLD];                                       // chunk i of this thread: panel row, byte offset in a plane
-#pragma unroll
-    for (int i = 0; i < NLD; i++) {
-        const int q = tid + NTH * i;
-        prow[i] = (4 * q) / H;
-        pdst[i] = prow[i] * ROWB + (4 * q - prow[i] * H) * 2;
-    }
-    for (int i = tid; i < 2 * 16 * ROWB / 4; i += NTH) reinterpret_cast<unsigned int *>(smem)[i] = 0u;
+    constexpr int NLD = 16 * H / 4 / NTH;                          // 16-byte chunks per thread and tile
+    static_assert(16 * H / 4 % NTH == 0 && H % 32 == 0, "panel must be whole passes of the workgroup");
     u64 *hxg = reinterpret_cast<u64 *>(a.hx);
     unsigned int *abortf = a.sync + 16;
     long long ph[6] = {0, 0, 0, 0, 0, 0}, tst = a.dbg ? (long long)__builtin_readcyclecounter() : 0;
@@ -612,13 +625,15 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_granule_kernel(PersistArgs 
         const int e = i * NTH + tid, r = e / UW, slot = e - r * UW, c = slot - r < 0 ? slot - r + UW : slot - r;
         grow[i] = r; gcol[i] = (d * 4 * H) + (member * UW + c) * 4;
     }
+    const unsigned wave_lds = __builtin_amdgcn_readfirstlane((unsigned)wave * 1024u);   // a wave's 1 KB slot inside a 4 KB LDS-DMA pass
+    const unsigned gx_lds = (unsigned)(unsigned long long)(lds_void_t *)Gx, rw_lds = (unsigned)(unsigned long long)(lds_void_t *)Rw;
     auto load_gx = [&](int bt, int par, int tt, int i0 = 0, int i1 = 99) {
         i1 = i1 > NGX ? NGX : i1;
         const float *gbase = a.gx + (size_t)tt * B * 2 * 4 * H;
 #pragma unroll
         for (int i = i0; i < i1; i++) {
             const int b = min(g * a.BGr + min(bt * 16 + grow[i], a.BGr - 1), B - 1);     // rows past the batch read a valid row (never used)
-            __builtin_amdgcn_global_load_lds(gbase + (size_t)b * 2 * 4 * H + gcol[i], (lds_void_t *)(Gx + (bt * 2 + par) * GXT + (i * NTH + wave * 64) * 4), 16, 0, 0);
+            lds_dma16_s<false>(gbase, (unsigned)(b * 2 * 4 * H + gcol[i]) * 4u, gx_lds + (unsigned)(((bt * 2 + par) * GXT + i * NTH * 4) * 4) + wave_lds);
         }
     };
     // Every wave issues exactly one store instruction per plane set (48 lanes x 16 bytes each; lanes of rows past the
@@ -651,35 +666,27 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_granule_kernel(PersistArgs 
         }
         return issued;
     };
-    // first-pass sweep request of (tile bt, step s): every chunk, unconditionally.  With one tile it goes to registers and
-    // is consumed at once.  Otherwise it is issued a phase ahead by LDS-DMA into the staging buffer (no registers held
-    // across the phase, and no compiler-inserted s_waitcnt vmcnt(0) at the point of use: the wave's memory counter is
-    // in-order, so waiting for the request with vmcnt(0) would also wait for the acknowledgement of every store issued
-    // after it -- the write-through publish alone takes ~1 us).  The request is waited for with vmcnt(K), K = the
-    // exact number of memory instructions this wave has issued since.
-    u32x4 pv[NLD];
-    auto request_sweep = [&](int bt, int s, int i0 = 0, int i1 = 99) {
+    // Sweep request of (tile bt, step s) into panel buffer pb: a linear LDS-DMA copy of the tile's panel (parity (s-1)&1),
+    // NLD pieces per wave.  With two or more tiles it is issued a phase ahead; it is waited for with vmcnt(K), K = the
+    // exact number of memory instructions this wave has issued since (the wave's memory counter is in-order: vmcnt(0)
+    // would also wait for the acknowledgement of every store issued after the request -- the write-through publish
+    // alone takes ~1 us).
+    auto request_sweep = [&](int bt, int s, int pb, int i0 = 0, int i1 = 99) {
         i1 = i1 > NLD ? NLD : i1;
-        const u64 *srcp = hxg + (size_t)(((s - 1) & 1) * 32 + team) * pgran + bt * tgran;
-        if (PF == 0) {
-            const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<u64 *>(srcp), 0, (int)(tgran * 8), 0x00020000);
+        const unsigned char *srcp = reinterpret_cast<const unsigned char *>(hxg + (size_t)(((s - 1) & 1) * 32 + team) * pgran + bt * tgran);
 #pragma unroll
-            for (int i = 0; i < NLD; i++) pv[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (tid + NTH * i) * 16, 0, 16 /* sc1 */);
-        } else {
-#pragma unroll
-            for (int i = i0; i < i1; i++)
-                __builtin_amdgcn_global_load_lds(reinterpret_cast<const unsigned char *>(srcp) + (size_t)(tid + NTH * i) * 16,
-                                                 (lds_void_t *)(Rw + (size_t)(i * NTH + wave * 64) * 16), 16, 0, 16 /* sc1 */);
-        }
+        for (int i = i0; i < i1; i++) lds_dma16_s<true>(srcp + (size_t)i * NTH * 16, (unsigned)tid * 16u, rw_lds + (unsigned)(pb * PANB + i * NTH * 16) + wave_lds);
     };
 #pragma unroll
     for (int bt = 0; bt < NBT; bt++) load_gx(bt, 0, d ? (T - 1) : 0);
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0), compiler-visible: the weight fragments are in registers from here on (no waits for them inside the loop)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     lds_barrier();
 
     int pend_bt = -1, pend_t = 0;                                   // PF == 0: the phase whose outputs still sit in the LDS tiles
-    bool requested = false;                                         // the first pass of the phase about to start is in flight / staged
+    bool requested = false;                                         // the panel of the phase about to start is in flight / staged
     int younger = 0;                                                // memory instructions this wave issued after that request
+    int pc = 0;                                                     // phases with a sweep so far: panel buffer = pc & 1
     for (int s = 0; s < T; s++) {
         const int t = d ? (T - 1 - s) : s;
 #pragma unroll
@@ -689,115 +696,125 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_granule_kernel(PersistArgs 
 #pragma unroll
             for (int rt = 0; rt < RTW; rt++) acc[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
             if (s > 0) {
-                // ---- sweep this thread's share of the tile's panel (parity (s-1)&1) until every tag is step s-1's
-                const u64 *srcp = hxg + (size_t)(((s - 1) & 1) * 32 + team) * pgran + bt * tgran;
-                const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<u64 *>(srcp), 0, (int)(tgran * 8), 0x00020000);
-                unsigned need = 0;
-                {
-                    const int nvr = a.BGr - bt * 16;                   // rows of this tile that exist in the team's batch group
-#pragma unroll
-                    for (int i = 0; i < NLD; i++) need |= (prow[i] < nvr ? 1u : 0u) << i;
-                }
+                const int pb = pc & 1;
+                ++pc;
                 const unsigned ep = (unsigned)((s - 1) % 3 + 1), etag = (ep & 1u) | ((ep >> 1) << 16);   // tag of step s-1: bit 0 in lo0, bit 1 in lo1
-                int sweeps = 0;
                 const long long t0 = wall_clock64();
-                if (!requested) {
-                    if (PF == 0) {
-                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // own publish acknowledged: a request sent earlier only finds stale tags
-                        request_sweep(bt, s);
-                        if (pend_bt >= 0) store_out(pend_bt, pend_t);   // the previous phase's outputs, behind the sweep in the queue
-                    } else {
-                        const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<u64 *>(srcp), 0, (int)(tgran * 8), 0x00020000);
+                // ---- the tile's panel of step s-1 -> LDS
+                if (PF == 0) {
+                    // one tile: nothing to overlap.  Each wave polls its own pieces (read back through LDS) until all tags match.
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // own publish acknowledged: a request sent earlier only finds stale tags
+                    request_sweep(bt, s, pb);
+                    wait_vmcnt(pend_bt >= 0 ? store_out(pend_bt, pend_t) : 0);   // the previous phase's outputs, behind the sweep in the queue
+                    int polls = 0;
+                    while (true) {
+                        unsigned bad = 0;
 #pragma unroll
-                        for (int i = 0; i < NLD; i++) pv[i] = __builtin_amdgcn_raw_buffer_load_b128(rs0, (tid + NTH * i) * 16, 0, 16 /* sc1 */);
+                        for (int i = 0; i < NLD; i++) {
+                            const u32x4 v = *reinterpret_cast<const u32x4 *>(Rw + (size_t)pb * PANB + (size_t)(i * NTH + tid) * 16);
+                            bad |= (v[2] ^ etag) | (v[3] ^ etag);
+                        }
+                        ++polls;
+                        if (!__any((bad & 0x00010001u) != 0)) break;
+                        if ((polls & 63) == 0) {
+                            int ab = 0;
+                            if (lane == 0) ab = (__hip_atomic_load(abortf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) || (wall_clock64() - t0 > 200000000ll);
+                            if (__any(ab)) {
+                                if (lane == 0) { __hip_atomic_store(abortf, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); atomicExch(a.err_flag, 2); s_fail = 1; }
+                                break;
+                            }
+                        }
+                        request_sweep(bt, s, pb);
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     }
-                } else {   // requested a phase ago by LDS-DMA: each lane reads back the chunks its own lane position fetched
-                    switch (younger) {
-                        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-                        case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
-                        case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
-                        default: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
-                    }
-#pragma unroll
-                    for (int i = 0; i < NLD; i++) pv[i] = *reinterpret_cast<const u32x4 *>(Rw + (size_t)(i * NTH + tid) * 16);
+                    if (a.dbg) ph[5] += polls;
+                } else {
+                    // requested a phase ago (or just now: the first step after s = 0)
+                    if (!requested) { request_sweep(bt, s, pb); younger = 0; }
+                    wait_vmcnt(younger);
                 }
                 requested = false;
-                while (true) {
-#pragma unroll
-                    for (int i = 0; i < NLD; i++) {
-                        // words (unit pairs): [hi0 | lo0'], [hi1 | lo1'] -> hi plane [hi0 | hi1], lo plane [lo0 | lo1] & ~tag bits
-                        const unsigned h0 = __builtin_amdgcn_perm(pv[i][1], pv[i][0], 0x05040100u), l0 = __builtin_amdgcn_perm(pv[i][1], pv[i][0], 0x07060302u);
-                        const unsigned h1 = __builtin_amdgcn_perm(pv[i][3], pv[i][2], 0x05040100u), l1 = __builtin_amdgcn_perm(pv[i][3], pv[i][2], 0x07060302u);
-                        if ((need & (1u << i)) && (l0 & 0x00010001u) == etag && (l1 & 0x00010001u) == etag) {
-                            need &= ~(1u << i);
-                            u32x2 vh, vl;
-                            vh[0] = h0; vh[1] = h1; vl[0] = l0 & 0xfffefffeu; vl[1] = l1 & 0xfffefffeu;
-                            *reinterpret_cast<u32x2 *>(Ph + pdst[i]) = vh;
-                            *reinterpret_cast<u32x2 *>(Pl + pdst[i]) = vl;
-                        }
-                    }
-                    ++sweeps;
-                    if (a.dbg && sweeps == 1) ph[1] += (long long)__builtin_readcyclecounter() - tst;   // first pass processed
-                    if (__all(need == 0)) break;
-                    if ((sweeps & 63) == 0) {
-                        int bad = 0;
-                        if (lane == 0) bad = (__hip_atomic_load(abortf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) || (wall_clock64() - t0 > 200000000ll);
-                        if (__any(bad)) {
-                            if (lane == 0) { __hip_atomic_store(abortf, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); atomicExch(a.err_flag, 2); s_fail = 1; }
-                            break;
-                        }
-                    }
-#pragma unroll
-                    for (int i = 0; i < NLD; i++)
-                        if (need & (1u << i)) pv[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (tid + NTH * i) * 16, 0, 16 /* sc1 */);
-                }
-                lds_barrier();
+                lds_barrier();                                          // every wave's pieces of the panel are in LDS
                 PSTAMP(0);
-                if (a.dbg) ph[5] += sweeps;
                 if (s_fail) return;
-                // this tile's next gx slab: into the other parity buffer, ahead of the sweep request below in the memory queue
-                // (the request's data is waited for with vmcnt(0): nothing slow may be younger than it)
                 // The LDS-DMA pieces of this phase -- this tile's next gx slab (other parity buffer), then, with three or more
                 // tiles, the next tile's sweep (its panel was published a whole phase ago) -- are issued one per k-step inside
                 // the MFMA loop: a piece costs the wave ~100 cycles of issue, which the MFMAs in flight cover.  The slab goes
                 // first: nothing slow may be younger than the sweep request (see the counted wait at its consumption).
                 const bool do_gx = s + 1 < T, do_rq = PF == 2 && ns < T;
-                // h fragments: PD reads ahead of the MFMAs that use them (a lone wave per SIMD hides no LDS latency otherwise)
-                constexpr int PD = 3;
-                bf16x8 qh[PD], ql[PD];
+                // The MFMA operands are built straight from the tagged words (no unpacking pass, no second copy in LDS):
+                // per k-step two 16-byte chunks -> 8 hi halves (one operand) and 8 lo halves (the other, tag bits cleared),
+                // 18 VALU instructions spread between the 3*RTW MFMAs of the k-step before.  The tags are summed on the
+                // way (bit 0 and bit 16 fields; 8*KS words per lane cannot overflow a field): with two or more tiles the
+                // panel was requested ahead and is used unchecked -- if the sum is off, some member's h had not landed
+                // when the request was served: every wave sees the same panel, so all take the same decision: request it
+                // again and redo the tile's products (never seen in practice: the request trails the publish by a phase).
+                const unsigned char *fb = Rw + (size_t)pb * PANB + kq * 512 + li * 16;
+                int tries = 0;
+                while (true) {
+                    constexpr int PD = 3;                             // chunk pairs read ahead of their use
+                    u32x4 ra[PD], rb[PD];
 #pragma unroll
-                for (int p = 0; p < PD; p++) {
-                    qh[p] = *reinterpret_cast<const bf16x8 *>(Ph + li * ROWB + p * 64 + kq * 16);
-                    ql[p] = *reinterpret_cast<const bf16x8 *>(Pl + li * ROWB + p * 64 + kq * 16);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int ks = 0; ks < KS; ks++) {
-                    const bf16x8 bh = qh[ks % PD], bl = ql[ks % PD];
-                    if (ks + PD < KS) {
-                        qh[ks % PD] = *reinterpret_cast<const bf16x8 *>(Ph + li * ROWB + (ks + PD) * 64 + kq * 16);
-                        ql[ks % PD] = *reinterpret_cast<const bf16x8 *>(Pl + li * ROWB + (ks + PD) * 64 + kq * 16);
+                    for (int p = 0; p < PD; p++) {
+                        ra[p] = *reinterpret_cast<const u32x4 *>(fb + p * 2048);
+                        rb[p] = *reinterpret_cast<const u32x4 *>(fb + p * 2048 + 256);
                     }
-                    if (ks < NGX) { if (do_gx) load_gx(bt, (s + 1) & 1, d ? (T - 2 - s) : (s + 1), ks, ks + 1); }
-                    else if (ks < NGX + NLD) { if (do_rq) request_sweep(nbt, ns, ks - NGX, ks - NGX + 1); }
-                    // product-major order: consecutive MFMAs hit different accumulators (no dependent-issue stall);
-                    // each accumulator still sees ah.bl, al.bh, ah.bh in that order (bit-identical to the step kernel)
-                    // (the scheduler would otherwise regroup them per accumulator into dependent back-to-back pairs)
-#pragma unroll
-                    for (int rt = 0; rt < RTW; rt++) acc[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[rt][ks], bl, acc[rt], 0, 0, 0);
+                    unsigned sraw = 0, smask = 0;                     // sums of the lo words with / without their tag bits
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int rt = 0; rt < RTW; rt++) mfma_a(acc[rt], al[rt][ks], bh);   // lo fragments stay in AGPRs and feed the MFMA from there
-                    __builtin_amdgcn_sched_barrier(0);
+                    for (int ks = 0; ks < KS; ks++) {
+                        const u32x4 xa = ra[ks % PD], xb = rb[ks % PD];
+                        if (ks + PD < KS) {
+                            ra[ks % PD] = *reinterpret_cast<const u32x4 *>(fb + (ks + PD) * 2048);
+                            rb[ks % PD] = *reinterpret_cast<const u32x4 *>(fb + (ks + PD) * 2048 + 256);
+                        }
+                        u32x4 hq, lq;
+                        hq[0] = xa[0]; hq[1] = xa[1]; hq[2] = xb[0]; hq[3] = xb[1];
+                        lq[0] = xa[2] & 0xfffefffeu; lq[1] = xa[3] & 0xfffefffeu; lq[2] = xb[2] & 0xfffefffeu; lq[3] = xb[3] & 0xfffefffeu;
+                        if (PF != 0) {
+                            sraw += xa[2] + xa[3]; sraw += xb[2] + xb[3];
+                            smask += lq[0] + lq[1]; smask += lq[2] + lq[3];
+                        }
+                        const bf16x8 bh = __builtin_bit_cast(bf16x8, hq), bl = __builtin_bit_cast(bf16x8, lq);
+                        if (tries == 0) {
+                            if (ks < NGX) { if (do_gx) load_gx(bt, (s + 1) & 1, d ? (T - 2 - s) : (s + 1), ks, ks + 1); }
+                            else if (ks < NGX + NLD) { if (do_rq) request_sweep(nbt, ns, pb ^ 1, ks - NGX, ks - NGX + 1); }
+                        }
+                        // product-major order: consecutive MFMAs hit different accumulators (no dependent-issue stall);
+                        // each accumulator still sees ah.bl, al.bh, ah.bh in that order (bit-identical to the step kernel)
+                        // (the scheduler would otherwise regroup them per accumulator into dependent back-to-back pairs)
 #pragma unroll
-                    for (int rt = 0; rt < RTW; rt++) acc[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[rt][ks], bh, acc[rt], 0, 0, 0);
-                    __builtin_amdgcn_sched_barrier(0);
+                        for (int rt = 0; rt < RTW; rt++) acc[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[rt][ks], bl, acc[rt], 0, 0, 0);
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int rt = 0; rt < RTW; rt++) mfma_a(acc[rt], al[rt][ks], bh);   // lo fragments stay in AGPRs and feed the MFMA from there
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int rt = 0; rt < RTW; rt++) acc[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[rt][ks], bh, acc[rt], 0, 0, 0);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    const unsigned tsum = sraw - smask;
+                    static_assert(NGX + NLD <= KS, "one LDS-DMA piece per k-step");
+                    if (PF == 0 || !__any(tsum != (unsigned)(8 * KS / 2) * etag)) break;
+                    // ---- stale panel (identical verdict in every wave): fetch it again, redo the products
+                    ++tries;
+                    if (a.dbg) ph[5] += 1;
+                    if (lane == 0 && ((__hip_atomic_load(abortf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) || (wall_clock64() - t0 > 200000000ll))) {
+                        __hip_atomic_store(abortf, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); atomicExch(a.err_flag, 2); s_fail = 1;
+                    }
+                    lds_barrier();                                      // every wave is done reading the panel; s_fail is visible
+                    if (s_fail) return;
+                    request_sweep(bt, s, pb);
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    lds_barrier();
+#pragma unroll
+                    for (int rt = 0; rt < RTW; rt++) acc[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
                 }
-                static_assert(NGX + NLD <= KS, "one LDS-DMA piece per k-step");
+                if (a.dbg && PF != 0) ph[5] += 1;
                 if (do_rq) requested = true;
-                int in_flight = (do_gx ? NGX : 0) + (do_rq ? NLD : 0);
+                int in_flight = tries ? 0 : ((do_gx ? NGX : 0) + (do_rq ? NLD : 0));
                 if (PF == 1 && ns < T) {   // two tiles: the other tile's panel has had the length of these MFMAs to arrive
-                    request_sweep(nbt, ns); requested = true;
+                    request_sweep(nbt, ns, pb ^ 1); requested = true;
                     in_flight += NLD;
                 }
                 wait_vmcnt(in_flight);   // everything older than this phase's pieces has landed: in particular this tile's current gx slab
@@ -806,12 +823,12 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_granule_kernel(PersistArgs 
             if (s == 0 && T > 1) load_gx(bt, 1, d ? (T - 2) : 1);
             PSTAMP(2);
             // ---- cell update; h_s goes to the LDS tiles (outputs, and tagged words for the team)
-            const unsigned tg = (unsigned)(s % 3 + 1), t0b = (tg & 1u) << 16, t1b = (tg >> 1) << 16;
+            const unsigned tg = (unsigned)(s % 3 + 1);
 #pragma unroll
             for (int rt = 0; rt < RTW; rt++) {
                 const int lb = bt * 16 + li, b = g * a.BGr + lb;
                 const bool valid = lb < a.BGr && b < B;
-                const int ul = (wave * RTW + rt) * 4 + kq;
+                const int cl = wave * RTW + rt, ul = cl * 4 + kq;        // chunk column and unit inside the workgroup's share
                 const int gslot = ul + li >= UW ? ul + li - UW : ul + li;
                 const float4 gv = *reinterpret_cast<const float4 *>(Gx + (bt * 2 + (s & 1)) * GXT + (li * UW + gslot) * 4);
                 const float ig = fast_sigmoid(acc[rt][0] + gv.x), fg = fast_sigmoid(acc[rt][1] + gv.y);
@@ -824,21 +841,22 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_granule_kernel(PersistArgs 
                 Oh[li * UW + ul] = *reinterpret_cast<unsigned short *>(&ob);
                 Ol[li * UW + ul] = *reinterpret_cast<unsigned short *>(&ol);
                 Of[li * UW + ul] = hn;
-                Og[li * UW + ul] = split_h(hn) | ((kq & 1) ? t1b : t0b);   // even unit: tag bit 0, odd unit: bit 1
+                const unsigned hw = split_h(hn);                       // chunk = {hi0 hi1 hi2 hi3 | lo0' lo1' lo2' lo3'}: tag bit 0 rides in the even units' lo, bit 1 in the odd units'
+                unsigned short *ogp = reinterpret_cast<unsigned short *>(Og) + (cl * 16 + li) * 8 + kq;
+                ogp[0] = (unsigned short)(hw & 0xffffu);
+                ogp[4] = (unsigned short)((hw >> 16) | ((kq & 1) ? (tg >> 1) : (tg & 1u)));
             }
             PSTAMP(3);
             lds_barrier();                                         // the tiles are complete; the gx slab is consumed
-            // ---- publish h_s (no drain, no signal): the workgroup's slice of every row is one 4*UW-byte run of whole
-            // 64-byte lines, written as 16-byte write-through stores (a lane-per-unit store is 16 partial lines per
-            // instruction, and a sweep that follows in the same in-order queue waits for every acknowledgement)
+            // ---- publish h_s (no drain, no signal): the workgroup's share of the tile's panel is one contiguous run of
+            // 16 * UW / 4 chunks, written as 16-byte write-through stores straight from the Og tile (same order)
             younger = 0;
-            if (s + 1 < T) {   // all 16 rows of the tile (rows past the batch carry zeros and valid tags; nobody sweeps them)
+            if (s + 1 < T) {   // all 16 rows of the tile (rows past the batch carry zeros and valid tags)
                 const __amdgpu_buffer_rsrc_t drs = __builtin_amdgcn_make_buffer_rsrc(hxg + (size_t)((s & 1) * 32 + team) * pgran + bt * tgran, 0, (int)(tgran * 8), 0x00020000);
-                constexpr int CG = UW / 4, PW = 16 * CG / 4;           // 16-byte chunks per row; chunks per wave
+                constexpr int PW = 16 * (UW / 4) / 4;                  // chunks per wave
                 if (lane < PW) {
-                    const int q = wave * PW + lane, r = q / CG, c = q - r * CG;
-                    __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4 *>(Og + r * UW + c * 4), drs,
-                                                           (r * (H / 2) + member * (UW / 2)) * 8 + c * 16, 0, 16 /* sc1 */);
+                    const int q = wave * PW + lane;
+                    __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4 *>(Og + q * 4), drs, (member * 16 * (UW / 4) + q) * 16, 0, 16 /* sc1 */);
                 }
                 younger++;
             }
@@ -861,8 +879,7 @@ int granule_bg(int B) { const int r = (B + 15) / 16; return (r + 15) / 16 * 16; 
 
 template <int H, int NBT, int RTW>
 static int launch_granule_t(PersistArgs a, hipStream_t st) {
-    constexpr int ROWB = H * 2 + 16;
-    const size_t smem = (size_t)2 * 16 * ROWB + (size_t)16 * (H / 8) * 12 + (size_t)NBT * 2 * 16 * (H / 8) * 16 + (NBT > 1 ? (size_t)16 * H * 4 : 0);   // h panel + tiles (2 bf16 planes, fp32, tagged words) + gx slabs (2 parities) + sweep staging
+    const size_t smem = (size_t)16 * (H / 8) * 12 + (size_t)NBT * 2 * 16 * (H / 8) * 16 + (size_t)2 * 16 * H * 4;   // tiles (2 bf16 planes, fp32, tagged words) + gx slabs (2 parities) + two panel buffers
     MDD_HIP_CHECK(hipMemsetAsync(a.sync, 0, 32 * sizeof(unsigned int), st));
     MDD_HIP_CHECK(hipMemsetAsync(a.hx, 0, (size_t)2 * 32 * NBT * 16 * H * 4, st));   // tags must start at 0 on every launch
     hipLaunchKernelGGL((lstm_layer_granule_kernel<H, NBT, RTW>), dim3(256), dim3(256), smem, st, a);
