@@ -636,36 +636,46 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_granule_kernel(PersistArgs 
             lds_dma16_s<false>(gbase, (unsigned)(b * 2 * 4 * H + gcol[i]) * 4u, gx_lds + (unsigned)(((bt * 2 + par) * GXT + i * NTH * 4) * 4) + wave_lds);
         }
     };
-    // Every wave issues exactly one store instruction per plane set (48 lanes x 16 bytes each; lanes of rows past the
-    // batch repeat the tile's last valid row: identical bytes to the same address), so that the number of memory
-    // operations a wave issues after a sweep request is known exactly -- see the counted wait below.
+    // Layer outputs and the publish leave as whole 16-byte chunks read back from the LDS tiles.  Every wave issues exactly
+    // one buffer store per destination (lanes without a chunk, and nothing else, are dropped by the buffer range check;
+    // lanes of rows past the batch repeat the tile's last valid row: identical bytes to the same address), so that the
+    // number of memory operations a wave issues after a sweep request is known exactly -- see the counted wait below.
+    // The LDS reads of a phase are issued together, ahead of the stores (one LDS round trip, not one per store).
+    constexpr int CH = UW / 8, CF = UW / 4;                           // 16-byte chunks per row: bf16 planes, fp32
+    constexpr int PWS = 2 * 16 * CH / 4, PWR = 16 * CF / 4, PWP = 16 * (UW / 4) / 4;   // chunks per wave: split planes (both), fp32, publish
+    static_assert((16 * CH) % PWS == 0 || PWS % (16 * CH) == 0, "a wave's split-plane chunks belong to one plane");
+    const int qs = wave * PWS + lane, pls = __builtin_amdgcn_readfirstlane(wave * PWS >= 16 * CH), qqs = qs - pls * 16 * CH, rs = qqs / CH, cs = qqs % CH;
+    const int qr = wave * PWR + lane, rr = qr / CF, cr = qr % CF;
+    const int qp = min(wave * PWP + lane, 16 * (UW / 4) - 1);
+    const unsigned offp = lane < PWP ? (unsigned)(member * 16 * (UW / 4) + wave * PWP + lane) * 16u : 0xffffffffu;
+    const size_t slab = (size_t)B * 2 * H;                              // elements of one time step of the layer output
     auto tile_rows = [&](int bt) { const int nv = min(a.BGr, B - g * a.BGr) - bt * 16; return nv < 0 ? 0 : (nv > 16 ? 16 : nv); };
-    auto store_out = [&](int bt, int tt) -> int {
-        constexpr int CH = UW / 8, CF = UW / 4;                       // 16-byte chunks per row: bf16 planes, fp32
-        const int nv = tile_rows(bt);
-        if (nv == 0) return 0;
+    struct OutRegs { u32x4 vs, vr; int r1, r2; };
+    auto out_read = [&](int bt, OutRegs &o) {
+        const int nv = max(tile_rows(bt), 1);
+        o.r1 = min(rs, nv - 1); o.r2 = min(rr, nv - 1);
+        if (a.out_split.hi) o.vs = *reinterpret_cast<const u32x4 *>((pls ? Ol : Oh) + o.r1 * UW + cs * 8);
+        if (a.out_raw) o.vr = *reinterpret_cast<const u32x4 *>(Of + o.r2 * UW + cr * 4);
+    };
+    auto out_write = [&](int bt, int tt, const OutRegs &o) -> int {
+        if (tile_rows(bt) == 0) return 0;
         int issued = 0;
+        const int b0 = g * a.BGr + bt * 16;
         if (a.out_split.hi) {
-            constexpr int PW = 2 * 16 * CH / 4;                       // chunks per wave (both planes over the 4 waves)
-            if (lane < PW) {
-                const int q = wave * PW + lane, pl = q >= 16 * CH, qq = pl ? q - 16 * CH : q, r = min(qq / CH, nv - 1), c = qq % CH;
-                const int b = g * a.BGr + bt * 16 + r;
-                const u32x4 v = *reinterpret_cast<const u32x4 *>((pl ? Ol : Oh) + r * UW + c * 8);
-                *reinterpret_cast<u32x4 *>((pl ? a.out_split.lo : a.out_split.hi) + ((size_t)tt * B + b) * 2 * H + d * H + member * UW + c * 8) = v;
-            }
+            const __amdgpu_buffer_rsrc_t rs_ = __builtin_amdgcn_make_buffer_rsrc((pls ? a.out_split.lo : a.out_split.hi) + (size_t)tt * slab, 0, (int)(slab * 2), 0x00020000);
+            const unsigned off = lane < PWS ? (unsigned)((b0 + o.r1) * 2 * H + d * H + member * UW + cs * 8) * 2u : 0xffffffffu;
+            __builtin_amdgcn_raw_buffer_store_b128(o.vs, rs_, off, 0, 0);
             issued++;
         }
         if (a.out_raw) {
-            constexpr int PW = 16 * CF / 4;
-            if (lane < PW) {
-                const int q = wave * PW + lane, r = min(q / CF, nv - 1), c = q % CF, b = g * a.BGr + bt * 16 + r;
-                *reinterpret_cast<u32x4 *>(a.out_raw + ((size_t)tt * B + b) * 2 * H + d * H + member * UW + c * 4) =
-                    *reinterpret_cast<const u32x4 *>(Of + r * UW + c * 4);
-            }
+            const __amdgpu_buffer_rsrc_t rs_ = __builtin_amdgcn_make_buffer_rsrc(a.out_raw + (size_t)tt * slab, 0, (int)(slab * 4), 0x00020000);
+            const unsigned off = lane < PWR ? (unsigned)((b0 + o.r2) * 2 * H + d * H + member * UW + cr * 4) * 4u : 0xffffffffu;
+            __builtin_amdgcn_raw_buffer_store_b128(o.vr, rs_, off, 0, 0);
             issued++;
         }
         return issued;
     };
+    auto store_out = [&](int bt, int tt) -> int { OutRegs o; out_read(bt, o); return out_write(bt, tt, o); };
     // Sweep request of (tile bt, step s) into panel buffer pb: a linear LDS-DMA copy of the tile's panel (parity (s-1)&1),
     // NLD pieces per wave.  With two or more tiles it is issued a phase ahead; it is waited for with vmcnt(K), K = the
     // exact number of memory instructions this wave has issued since (the wave's memory counter is in-order: vmcnt(0)
@@ -811,6 +821,7 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_granule_kernel(PersistArgs 
                     for (int rt = 0; rt < RTW; rt++) acc[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
                 }
                 if (a.dbg && PF != 0) ph[5] += 1;
+                const long long tpl = a.dbg ? (long long)__builtin_readcyclecounter() : 0;
                 if (do_rq) requested = true;
                 int in_flight = tries ? 0 : ((do_gx ? NGX : 0) + (do_rq ? NLD : 0));
                 if (PF == 1 && ns < T) {   // two tiles: the other tile's panel has had the length of these MFMAs to arrive
@@ -818,30 +829,41 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_granule_kernel(PersistArgs 
                     in_flight += NLD;
                 }
                 wait_vmcnt(in_flight);   // everything older than this phase's pieces has landed: in particular this tile's current gx slab
+                if (a.dbg) ph[1] += (long long)__builtin_readcyclecounter() - tpl;
                 lds_barrier();   // every wave is done with the LDS panel; every wave's part of the gx slab is in LDS
             }
             if (s == 0 && T > 1) load_gx(bt, 1, d ? (T - 2) : 1);
             PSTAMP(2);
             // ---- cell update; h_s goes to the LDS tiles (outputs, and tagged words for the team)
             const unsigned tg = (unsigned)(s % 3 + 1);
+            const int lb = bt * 16 + li;
+            const bool valid = lb < a.BGr && g * a.BGr + lb < B;
+            float4 gv[RTW];
+            float hn[RTW];
+#pragma unroll
+            for (int rt = 0; rt < RTW; rt++) {   // the three slab reads together: one LDS round trip
+                const int ul = (wave * RTW + rt) * 4 + kq;
+                const int gslot = ul + li >= UW ? ul + li - UW : ul + li;
+                gv[rt] = *reinterpret_cast<const float4 *>(Gx + (bt * 2 + (s & 1)) * GXT + (li * UW + gslot) * 4);
+            }
+#pragma unroll
+            for (int rt = 0; rt < RTW; rt++) {   // branch-free: the row tiles' chains interleave
+                const float ig = fast_sigmoid(acc[rt][0] + gv[rt].x), fg = fast_sigmoid(acc[rt][1] + gv[rt].y);
+                const float cg = fast_tanh(acc[rt][2] + gv[rt].z), og = fast_sigmoid(acc[rt][3] + gv[rt].w);
+                const float cn = fg * cst[rt][bt] + ig * cg;
+                const float hr = og * fast_tanh(cn);
+                hn[rt] = valid ? hr : 0.f;
+                cst[rt][bt] = cn;
+            }
 #pragma unroll
             for (int rt = 0; rt < RTW; rt++) {
-                const int lb = bt * 16 + li, b = g * a.BGr + lb;
-                const bool valid = lb < a.BGr && b < B;
                 const int cl = wave * RTW + rt, ul = cl * 4 + kq;        // chunk column and unit inside the workgroup's share
-                const int gslot = ul + li >= UW ? ul + li - UW : ul + li;
-                const float4 gv = *reinterpret_cast<const float4 *>(Gx + (bt * 2 + (s & 1)) * GXT + (li * UW + gslot) * 4);
-                const float ig = fast_sigmoid(acc[rt][0] + gv.x), fg = fast_sigmoid(acc[rt][1] + gv.y);
-                const float cg = fast_tanh(acc[rt][2] + gv.z), og = fast_sigmoid(acc[rt][3] + gv.w);
-                const float cn = fg * cst[rt][bt] + ig * cg;
-                const float hn = valid ? og * fast_tanh(cn) : 0.f;
-                cst[rt][bt] = cn;
-                const float ov = hn * osc[rt] + osh[rt];
+                const float ov = hn[rt] * osc[rt] + osh[rt];
                 __bf16 ob = (__bf16)ov, ol = (__bf16)(ov - (float)ob);
                 Oh[li * UW + ul] = *reinterpret_cast<unsigned short *>(&ob);
                 Ol[li * UW + ul] = *reinterpret_cast<unsigned short *>(&ol);
-                Of[li * UW + ul] = hn;
-                const unsigned hw = split_h(hn);                       // chunk = {hi0 hi1 hi2 hi3 | lo0' lo1' lo2' lo3'}: tag bit 0 rides in the even units' lo, bit 1 in the odd units'
+                Of[li * UW + ul] = hn[rt];
+                const unsigned hw = split_h(hn[rt]);                   // chunk = {hi0 hi1 hi2 hi3 | lo0' lo1' lo2' lo3'}: tag bit 0 rides in the even units' lo, bit 1 in the odd units'
                 unsigned short *ogp = reinterpret_cast<unsigned short *>(Og) + (cl * 16 + li) * 8 + kq;
                 ogp[0] = (unsigned short)(hw & 0xffffu);
                 ogp[4] = (unsigned short)((hw >> 16) | ((kq & 1) ? (tg >> 1) : (tg & 1u)));
@@ -851,19 +873,21 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_granule_kernel(PersistArgs 
             // ---- publish h_s (no drain, no signal): the workgroup's share of the tile's panel is one contiguous run of
             // 16 * UW / 4 chunks, written as 16-byte write-through stores straight from the Og tile (same order)
             younger = 0;
-            if (s + 1 < T) {   // all 16 rows of the tile (rows past the batch carry zeros and valid tags)
-                const __amdgpu_buffer_rsrc_t drs = __builtin_amdgcn_make_buffer_rsrc(hxg + (size_t)((s & 1) * 32 + team) * pgran + bt * tgran, 0, (int)(tgran * 8), 0x00020000);
-                constexpr int PW = 16 * (UW / 4) / 4;                  // chunks per wave
-                if (lane < PW) {
-                    const int q = wave * PW + lane;
-                    __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4 *>(Og + q * 4), drs, (member * 16 * (UW / 4) + q) * 16, 0, 16 /* sc1 */);
+            {
+                const bool pub = s + 1 < T, defer = PF == 0 && s > 0 && s + 1 < T;
+                const u32x4 pv = *reinterpret_cast<const u32x4 *>(Og + qp * 4);
+                OutRegs o;
+                if (!defer) out_read(bt, o);
+                if (pub) {   // all 16 rows of the tile (rows past the batch carry zeros and valid tags)
+                    const __amdgpu_buffer_rsrc_t drs = __builtin_amdgcn_make_buffer_rsrc(hxg + (size_t)((s & 1) * 32 + team) * pgran + bt * tgran, 0, (int)(tgran * 8), 0x00020000);
+                    __builtin_amdgcn_raw_buffer_store_b128(pv, drs, offp, 0, 16 /* sc1 */);
+                    younger++;
                 }
-                younger++;
+                // layer outputs: with one tile they wait for the next sweep's request (nothing else to hide them behind);
+                // otherwise the next sweep is already in flight and they go out now
+                if (defer) { pend_bt = bt; pend_t = t; }
+                else { younger += out_write(bt, t, o); pend_bt = -1; }
             }
-            // layer outputs: with one tile they wait for the next sweep's request (nothing else to hide them behind);
-            // otherwise the next sweep is already in flight and they go out now
-            if (PF == 0 && s > 0 && s + 1 < T) { pend_bt = bt; pend_t = t; }
-            else { younger += store_out(bt, t); pend_bt = -1; }
             if (s == 0) {   // no MFMA section with its barriers follows before these LDS regions are reused
                 if (bt + 1 == NBT) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 lds_barrier();
