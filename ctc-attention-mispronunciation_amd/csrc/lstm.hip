@@ -499,19 +499,22 @@ __device__ __forceinline__ void mfma_a(f32x4 &acc, const bf16x8 &a_agpr, const b
 // ---- persistent layer kernel, data-tagged hand-off ("the data IS the flag", Guideline 16 form R2).
 // Same team structure, but (1) a team is 8 workgroups (32 teams = 2 directions x 16 batch groups), each workgroup
 // owning 4H/8 gate rows: RTW row tiles per wave, fragments resident in registers; the panel a workgroup pulls per
-// step is half as tall; (2) h travels as 8-byte granules of TWO units {hi0 | lo0 << 16, hi1 | lo1 << 16} whose epoch
-// tag (1..3 = step % 3 + 1) rides in the two spare last bits of lo0 and lo1 (split_h clears them): the producer just
-// stores them write-through -- no drain, no barrier, no counter -- and the consumer re-reads its share of the panel
-// until every tag equals the epoch.  One L2 round trip replaces three (drain, counter add, poll).  A panel of one
-// parity only ever holds step s or step s-2 (nobody publishes step s before everyone has read s-2), whose tags
-// differ; the exchange buffer is zeroed before every launch (tag 0 is never valid), so replays cannot see a previous
-// launch's data.  The sweep is bound by the bytes all 256 workgroups pull past their L2s (measured: ~110 cycles per
-// KB of panel), hence the dense format: 4 bytes per unit and row, and only the team's real batch rows.
+// step is half as tall; (2) h travels as 16-byte chunks of FOUR units of one batch row, {hi0 hi1 hi2 hi3 | lo0 lo1 lo2
+// lo3}, whose epoch tag (1..3 = step % 3 + 1) rides in the spare last bits of the lo halves (split_h clears them: bit 0
+// of the tag in the even units, bit 1 in the odd ones): the producer just stores them write-through -- no drain, no
+// barrier, no counter -- and the consumer checks the tags of what it fetched ("the data IS the flag").  A chunk is one
+// lane's single 16-byte store, so a chunk is either old or new as a whole.  One L2 round trip replaces three (drain,
+// counter add, poll).  A panel of one parity only ever holds step s or step s-2 (nobody publishes step s before
+// everyone has read s-2), whose tags differ; the exchange buffer is zeroed before every launch (tag 0 is never valid),
+// so replays cannot see a previous launch's data.  The hand-off is bound by the bytes all 256 workgroups pull past
+// their L2s and by the ~2 us a write-through store takes to become visible, hence the dense format (4 bytes per unit
+// and row) and the chunk order = (unit / 4) * 16 + row: a workgroup's share is one contiguous run, the sweep a linear
+// LDS-DMA copy, and the chunks are the MFMA operands as they lie (see the kernel body).
 // A team's batch rows come in NBT tiles of 16 (one MFMA column tile each).  The tiles are independent recurrences and
 // are advanced in turn, each with its own panel and epoch: while one tile's h_s travels to the team (the hand-off is
 // ~2 us of pure latency), the workgroup runs the other tiles' MFMAs and cell updates.  With three or more tiles a
 // tile's panel has been complete for a whole phase when its turn comes, so its sweep is requested one phase AHEAD
-// (into registers, behind nothing in the memory queue) and costs only the tag check; with two tiles it is requested
+// (LDS-DMA into the other panel buffer, one piece per k-step of the MFMA loop); with two tiles it is requested
 // after the MFMAs of the phase before (the panel is not complete earlier); with one there is nothing to overlap.
 // The gate pre-activations never occupy registers: each tile's next [16 rows x 4*UW] slab is fetched by LDS-DMA as
 // soon as the cell update has consumed the current one.
@@ -752,13 +755,13 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_granule_kernel(PersistArgs 
                 // the MFMA loop: a piece costs the wave ~100 cycles of issue, which the MFMAs in flight cover.  The slab goes
                 // first: nothing slow may be younger than the sweep request (see the counted wait at its consumption).
                 const bool do_gx = s + 1 < T, do_rq = PF == 2 && ns < T;
-                // The MFMA operands are built straight from the tagged words (no unpacking pass, no second copy in LDS):
-                // per k-step two 16-byte chunks -> 8 hi halves (one operand) and 8 lo halves (the other, tag bits cleared),
-                // 18 VALU instructions spread between the 3*RTW MFMAs of the k-step before.  The tags are summed on the
-                // way (bit 0 and bit 16 fields; 8*KS words per lane cannot overflow a field): with two or more tiles the
-                // panel was requested ahead and is used unchecked -- if the sum is off, some member's h had not landed
-                // when the request was served: every wave sees the same panel, so all take the same decision: request it
-                // again and redo the tile's products (never seen in practice: the request trails the publish by a phase).
+                // The MFMA operands come straight from the travelling chunks (no unpacking pass, no second copy in LDS): per
+                // k-step two 16-byte chunks {hi x4 | lo' x4} -> the hi halves of both are one operand, the lo halves (tag
+                // bits cleared: 4 v_and) the other.  One tagged word per chunk is summed on the way (bit 0 and bit 16
+                // fields; 2*KS words per lane cannot overflow a field).  With two or more tiles the panel was requested
+                // ahead and is used unchecked: if the sum is off, some member's h had not landed when the request was
+                // served; every wave sees the same panel, so all take the same decision: request it again and redo the
+                // tile's products (not seen with the request placed after the MFMAs: it trails the publish by ~2 us).
                 const unsigned char *fb = Rw + (size_t)pb * PANB + kq * 512 + li * 16;
                 int tries = 0;
                 while (true) {
@@ -781,10 +784,7 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_granule_kernel(PersistArgs 
                         u32x4 hq, lq;
                         hq[0] = xa[0]; hq[1] = xa[1]; hq[2] = xb[0]; hq[3] = xb[1];
                         lq[0] = xa[2] & 0xfffefffeu; lq[1] = xa[3] & 0xfffefffeu; lq[2] = xb[2] & 0xfffefffeu; lq[3] = xb[3] & 0xfffefffeu;
-                        if (PF != 0) {
-                            sraw += xa[2] + xa[3]; sraw += xb[2] + xb[3];
-                            smask += lq[0] + lq[1]; smask += lq[2] + lq[3];
-                        }
+                        if (PF != 0) { sraw += xa[2] + xb[2]; smask += lq[0] + lq[2]; }   // one tagged word per 16-byte chunk: a chunk is one lane's single store
                         const bf16x8 bh = __builtin_bit_cast(bf16x8, hq), bl = __builtin_bit_cast(bf16x8, lq);
                         if (tries == 0) {
                             if (ks < NGX) { if (do_gx) load_gx(bt, (s + 1) & 1, d ? (T - 2 - s) : (s + 1), ks, ks + 1); }
@@ -805,7 +805,7 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_granule_kernel(PersistArgs 
                     }
                     const unsigned tsum = sraw - smask;
                     static_assert(NGX + NLD <= KS, "one LDS-DMA piece per k-step");
-                    if (PF == 0 || !__any(tsum != (unsigned)(8 * KS / 2) * etag)) break;
+                    if (PF == 0 || !__any(tsum != (unsigned)(2 * KS) * etag)) break;
                     // ---- stale panel (identical verdict in every wave): fetch it again, redo the products
                     ++tries;
                     if (a.dbg) ph[5] += 1;
