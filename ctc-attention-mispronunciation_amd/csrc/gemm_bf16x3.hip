@@ -474,20 +474,33 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16x3_ph8_kernel(const unsigned 
             for (int i = 0; i < 4; i++)
 #pragma unroll
                 for (int j = 0; j < 2; j++) acc[a][b][i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    // half-tile ht of the K-tile at k0 -> stage: 0 = A half 0, 1 = W half 0, 2 = W half 1, 3 = A half 1; this wave's 2 pieces
-    auto issue = [&](int ht, int k0, unsigned char *stage) {
+    // half-tile ht of the K-tile at k0 -> stage: 0 = A half 0, 1 = W half 0, 2 = W half 1, 3 = A half 1; this wave's 2 pieces.
+    // Addresses are a wave-uniform base (SGPR pair, advanced by k0) plus a per-lane 32-bit byte offset fixed for the
+    // whole K loop, and the LDS address is scalar too: no vector address arithmetic inside the loop (on this chip a
+    // SIMD's vector instructions are not covered by its MFMAs).
+    const unsigned wave_s = __builtin_amdgcn_readfirstlane((unsigned)wave);
+    const unsigned lds0 = (unsigned)(unsigned long long)(lds_void *)glds_smem;
+    unsigned voff[4];
+#pragma unroll
+    for (int ht = 0; ht < 4; ht++) {
         const bool isA = ht == 0 || ht == 3;
         const int half = (ht >= 2) ? 1 : 0, g = half * 8 + wave;     // 16-row group inside the plane
         const int row = g * 16 + (lane >> 2), cp = lane & 3, c = cp ^ ((row >> 2) & 3);
         const int ld = isA ? lda : ldw, rtot = isA ? M : N, r0 = isA ? m0 : n0;
-        const size_t off = (size_t)min(r0 + row, rtot - 1) * ld + k0 + c * 8;
-        __builtin_amdgcn_global_load_lds((isA ? Ah : Wh) + off, (lds_void *)(stage + (isA ? 0 : 2) * PL + g * 1024), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((isA ? Al : Wl) + off, (lds_void *)(stage + (isA ? 1 : 3) * PL + g * 1024), 16, 0, 0);
+        voff[ht] = (unsigned)(((size_t)min(r0 + row, rtot - 1) * ld + c * 8) * 2);
+    }
+    auto issue = [&](int ht, int k0, unsigned stage_off) {
+        const bool isA = ht == 0 || ht == 3;
+        const unsigned g = ((ht >= 2) ? 8u : 0u) + wave_s;
+        const unsigned short *bh = (isA ? Ah : Wh) + k0, *bl = (isA ? Al : Wl) + k0;
+        const unsigned la = lds0 + stage_off + g * 1024u;
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(voff[ht]), "s"(bh), "s"(la + (unsigned)((isA ? 0 : 2) * PL)) : "memory", "m0");
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(voff[ht]), "s"(bl), "s"(la + (unsigned)((isA ? 1 : 3) * PL)) : "memory", "m0");
     };
     const int nk = K / XBK;
     const int l16 = lane & 15, kq16 = (lane >> 4) * 16;
 #pragma unroll
-    for (int ht = 0; ht < 4; ht++) issue(ht, 0, glds_smem);
+    for (int ht = 0; ht < 4; ht++) issue(ht, 0, 0u);
     asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                 // A0, W0 of K-tile 0
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     if (grp == 1) asm volatile("s_barrier" ::: "memory");            // from here on one barrier behind group 0
@@ -504,7 +517,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16x3_ph8_kernel(const unsigned 
             _Pragma("unroll") for (int j = 0; j < 2; j++) acc[a_][b_][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fah[i], fwh[b_][j], acc[a_][b_][i][j], 0, 0, 0); }
     for (int kt = 0; kt < nk; kt++) {
         const unsigned char *st = glds_smem + (kt & 1) * 4 * PL;
-        unsigned char *nst = glds_smem + ((kt & 1) ^ 1) * 4 * PL;
+        const unsigned nst = (unsigned)(((kt & 1) ^ 1) * 4 * PL);   // byte offset of the other stage
         const bool more = kt + 1 < nk;
         const int nk0 = (kt + 1) * XBK;
         // ---- quadrant (0,0)
