@@ -646,9 +646,9 @@ extern "C" int mdd_diag_gemm(int M, int N, int K, int abl, int iters, float *ms_
     MDD_HIP_CHECK(hipMemset(W, 0x3b, (size_t)2 * N * LD * 2));
     const int tiles_m = (M + XBM - 1) / XBM, tiles_n = (N + XBN - 1) / XBN;
     dim3 grid(tiles_m * tiles_n, 1, 1), block(256);
-    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    hipEvent_t e0, e1; MDD_HIP_CHECK(hipEventCreate(&e0)); MDD_HIP_CHECK(hipEventCreate(&e1));
     for (int it = -1; it < iters; it++) {
-        if (it == 0) hipEventRecord(e0, nullptr);
+        if (it == 0) MDD_HIP_CHECK(hipEventRecord(e0, nullptr));
 #define LAUNCH_ABL(X) hipLaunchKernelGGL((gemm_bf16x3_kernel<0, X>), grid, block, 0, nullptr, A, A + (size_t)M * K, W, W + (size_t)N * K, (const float *)nullptr, C, \
                                           (unsigned short *)nullptr, (unsigned short *)nullptr, M, N, K, K, K, N, 0l, 0l, 0l, tiles_n)
         if (abl == 9) {
@@ -674,9 +674,9 @@ extern "C" int mdd_diag_gemm(int M, int N, int K, int abl, int iters, float *ms_
                        case 6: LAUNCH_ABL(6); break; default: LAUNCH_ABL(7); }
 #undef LAUNCH_ABL
     }
-    hipEventRecord(e1, nullptr); hipEventSynchronize(e1);
-    float t = 0; hipEventElapsedTime(&t, e0, e1); *ms_out = t / iters;
-    hipFree(A); hipFree(W); hipFree(C); hipEventDestroy(e0); hipEventDestroy(e1);
+    MDD_HIP_CHECK(hipEventRecord(e1, nullptr)); MDD_HIP_CHECK(hipEventSynchronize(e1));
+    float t = 0; MDD_HIP_CHECK(hipEventElapsedTime(&t, e0, e1)); *ms_out = t / iters;
+    (void)hipFree(A); (void)hipFree(W); (void)hipFree(C); (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     return MDD_OK;
 }
 namespace mdd {

@@ -4,13 +4,18 @@
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define ITERS 20000
-template <int NACC, int MODE>   // MODE 0: all VGPR; 1: acc in AGPR (asm); 2: acc+A in AGPR (asm); 3: VGPR with 2 VALU after each MFMA
+template <int NACC, int MODE>   // MODE 4: one ds_read_b128 per 4 MFMAs; 5: same + s_barrier per 24 MFMAs; MODE 0: all VGPR; 1: acc in AGPR (asm); 2: acc+A in AGPR (asm); 3: VGPR with 2 VALU after each MFMA
 __global__ void k(long long *out, float *sink, unsigned seed) {
     bf16x8 a, b;
     for (int i = 0; i < 8; i++) { a[i] = (__bf16)(float)((threadIdx.x + i) & 3); b[i] = (__bf16)(float)((threadIdx.x * 3 + i) & 3); }
     f32x4 acc[NACC];
     for (int i = 0; i < NACC; i++) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
     unsigned x = seed + threadIdx.x, y = seed * 3 + 1, z = 0;
+    __shared__ __attribute__((aligned(16))) unsigned lds[8192];
+    for (int i = threadIdx.x; i < 8192; i += blockDim.x) lds[i] = i;
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 lv = {0, 0, 0, 0};
+    int cnt = 0;
     __syncthreads();
     long long t0 = __builtin_readcyclecounter();
     for (int it = 0; it < ITERS; it++) {
@@ -18,16 +23,18 @@ __global__ void k(long long *out, float *sink, unsigned seed) {
         for (int r = 0; r < 12 / NACC; r++)
 #pragma unroll
             for (int i = 0; i < NACC; i++) {
-                if (MODE == 0 || MODE == 3) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[i], 0, 0, 0);
+                if (MODE == 0 || MODE >= 3) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[i], 0, 0, 0);
                 else if (MODE == 1) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[i]) : "v"(a), "v"(b));
                 else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[i]) : "a"(a), "v"(b));
+                if (MODE >= 4 && ((r * NACC + i) & 3) == 0) { const u32x4 t = *reinterpret_cast<const u32x4 *>(&lds[((threadIdx.x * 4 + it * 64) & 8188)]); lv[0] ^= t[0]; lv[1] ^= t[3]; }
+                if (MODE == 5 && (r * NACC + i) == 0 && (it & 1) == 0) asm volatile("s_barrier" ::: "memory");
                 if (MODE == 3) { z = __builtin_amdgcn_perm(x, y, 0x05040100u) + z; x = __builtin_amdgcn_perm(y, z, 0x07060302u); }
                 __builtin_amdgcn_sched_barrier(0);
             }
     }
     long long t1 = __builtin_readcyclecounter();
     float s = 0; for (int i = 0; i < NACC; i++) s += acc[i][0] + acc[i][3];
-    sink[blockIdx.x * blockDim.x + threadIdx.x] = s + (float)(x + z);
+    sink[blockIdx.x * blockDim.x + threadIdx.x] = s + (float)(x + z + lv[0] + lv[1]);
     if (threadIdx.x == 0 && blockIdx.x == 0) out[0] = t1 - t0;
 }
 template <int NACC, int MODE> void run(const char *name, int threads, long long *d_out, float *sink) {
@@ -50,6 +57,8 @@ int main() {
     run<3, 3>("3 acc, VGPR, 2 VALU after each", 256, d, sink); run<12, 3>("12 acc, VGPR, 2 VALU after each", 256, d, sink);
     run<3, 0>("3 acc, VGPR", 512, d, sink); run<12, 0>("12 acc, VGPR", 512, d, sink); run<3, 3>("3 acc, VGPR, 2 VALU after each", 512, d, sink);
     run<1, 0>("1 acc (dependent chain), VGPR", 256, d, sink); run<2, 0>("2 acc, VGPR", 256, d, sink);
+    run<12, 4>("12 acc, 1 ds_read_b128 per 4 MFMA", 256, d, sink); run<12, 4>("12 acc, 1 ds_read_b128 per 4 MFMA", 512, d, sink);
+    run<12, 5>("12 acc, ds_read + barrier per 24 MFMA", 256, d, sink); run<12, 5>("12 acc, ds_read + barrier per 24 MFMA", 512, d, sink);
     run<3, 0>("3 acc, VGPR", 768, d, sink); run<3, 0>("3 acc, VGPR", 1024, d, sink); run<3, 3>("3 acc, VGPR, 2 VALU after each", 1024, d, sink);
     return 0;
 }
