@@ -320,6 +320,7 @@ struct PersistArgs {
     const float *oscale, *oshift;
     int T, B, BG, BGr;               // BG: padded rows per group (multiple of 16), BGr: real rows per group
     long long *dbg;                  // diagnostic builds only: per-workgroup cycle sums of the step phases (null in production)
+    int early;                       // diagnostic (MDD_LSTM_EARLY): request the next tile's panel a whole MFMA section too early, so that stale panels and the redo path occur
 };
 
 typedef unsigned long long u64;
@@ -698,7 +699,7 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_granule_kernel(PersistArgs 
 
     int pend_bt = -1, pend_t = 0;                                   // PF == 0: the phase whose outputs still sit in the LDS tiles
     bool requested = false;                                         // the panel of the phase about to start is in flight / staged
-    int younger = 0;                                                // memory instructions this wave issued after that request
+    int younger = 0, early_gx = 0;                                  // memory instructions this wave issued after that request
     int pc = 0;                                                     // phases with a sweep so far: panel buffer = pc & 1
     for (int s = 0; s < T; s++) {
         const int t = d ? (T - 1 - s) : s;
@@ -754,7 +755,9 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_granule_kernel(PersistArgs 
                 // tiles, the next tile's sweep (its panel was published a whole phase ago) -- are issued one per k-step inside
                 // the MFMA loop: a piece costs the wave ~100 cycles of issue, which the MFMAs in flight cover.  The slab goes
                 // first: nothing slow may be younger than the sweep request (see the counted wait at its consumption).
-                const bool do_gx = s + 1 < T, do_rq = PF == 2 && ns < T;
+                const bool early = PF != 0 && a.early && ns < T;
+                if (early) { request_sweep(nbt, ns, pb ^ 1); requested = true; }
+                const bool do_gx = s + 1 < T, do_rq = PF == 2 && ns < T && !early;
                 // The MFMA operands come straight from the travelling chunks (no unpacking pass, no second copy in LDS): per
                 // k-step two 16-byte chunks {hi x4 | lo' x4} -> the hi halves of both are one operand, the lo halves (tag
                 // bits cleared: 4 v_and) the other.  One tagged word per chunk is summed on the way (bit 0 and bit 16
@@ -823,8 +826,9 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_granule_kernel(PersistArgs 
                 if (a.dbg && PF != 0) ph[5] += 1;
                 const long long tpl = a.dbg ? (long long)__builtin_readcyclecounter() : 0;
                 if (do_rq) requested = true;
-                int in_flight = tries ? 0 : ((do_gx ? NGX : 0) + (do_rq ? NLD : 0));
-                if (PF == 1 && ns < T) {   // two tiles: the other tile's panel has had the length of these MFMAs to arrive
+                int in_flight = tries ? 0 : ((do_gx ? NGX : 0) + ((do_rq || early) ? NLD : 0));
+                early_gx = (early && do_gx && !tries) ? NGX : 0;       // memory instructions younger than an early request
+                if (PF == 1 && ns < T && !early) {   // two tiles: the other tile's panel has had the length of these MFMAs to arrive
                     request_sweep(nbt, ns, pb ^ 1); requested = true;
                     in_flight += NLD;
                 }
@@ -872,7 +876,7 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_granule_kernel(PersistArgs 
             lds_barrier();                                         // the tiles are complete; the gx slab is consumed
             // ---- publish h_s (no drain, no signal): the workgroup's share of the tile's panel is one contiguous run of
             // 16 * UW / 4 chunks, written as 16-byte write-through stores straight from the Og tile (same order)
-            younger = 0;
+            younger = early_gx; early_gx = 0;
             {
                 const bool pub = s + 1 < T, defer = PF == 0 && s > 0 && s + 1 < T;
                 const u32x4 pv = *reinterpret_cast<const u32x4 *>(Og + qp * 4);
@@ -917,6 +921,7 @@ int launch_lstm_layer_granule(const LstmStepArgs &s, unsigned short *hx, unsigne
     a.out = s.out; a.out_raw = s.out_raw; a.out_split = s.out_split; a.oscale = s.oscale; a.oshift = s.oshift;
     a.T = s.T; a.B = s.B; a.BGr = (s.B + 15) / 16; a.BG = granule_bg(s.B);
     a.dbg = (getenv("MDD_LSTM_DBG") && s.T > 100) ? reinterpret_cast<long long *>(reinterpret_cast<u64 *>(hx) + (size_t)2 * 32 * a.BG * s.H) : nullptr;
+    a.early = getenv("MDD_LSTM_EARLY") != nullptr;
     if (a.oscale == nullptr) a.oshift = nullptr;
     if (a.out && a.out != a.out_raw) { set_error("granule lstm: a separate scaled fp32 output is not supported (split planes carry it)"); return MDD_ERR_ARG; }
     const int nbt = a.BG / 16;
@@ -954,6 +959,7 @@ int launch_lstm_layer_persistent(const LstmStepArgs &s, unsigned short *hx, unsi
     a.out = s.out; a.out_raw = s.out_raw; a.out_split = s.out_split; a.oscale = s.oscale; a.oshift = s.oshift;
     a.T = s.T; a.B = s.B; a.BGr = (s.B + 7) / 8; a.BG = persistent_bg(s.B);
     a.dbg = (getenv("MDD_LSTM_DBG") && s.T > 100) ? reinterpret_cast<long long *>(hx + (size_t)2 * 16 * 2 * a.BG * s.H) : nullptr;
+    a.early = 0;
     const int nbt = a.BG / 16;
     if (s.H == 384) {
         if (nbt == 1) return launch_persistent_t<384, 1>(a, st);

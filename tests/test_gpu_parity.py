@@ -269,6 +269,26 @@ def test_persistent_lstm_batch_sizes_match_step_kernels(B, monkeypatch):
         np.testing.assert_array_equal(got2, ref)
 
 
+@pytest.mark.parametrize("B", [512, 700])
+def test_persistent_lstm_stale_panel_redo_path(B, monkeypatch):
+    """The BiLSTM uses a panel requested ahead without checking it first and redoes the tile's products when the tags
+    summed on the way say it was stale.  With the request placed where it normally is that never happens, so the
+    diagnostic switch MDD_LSTM_EARLY moves it a whole MFMA section earlier: redos must occur, results must not move."""
+    geom = synth.Geometry(**synth.REFERENCE)
+    sd = synth.synth_state_dict(geom, seed=78)
+    x, x1, _, _ = synth.synth_batch(geom, B=B, T=420, L=6, seed=B, ragged=False)
+    ref = _hip().HipModel(geom, sd, precision="bf16x3").forward(_cuda(x), _cuda(x1), sync_errors=True).cpu().numpy()
+    monkeypatch.setenv("MDD_LSTM_EARLY", "1")
+    monkeypatch.setenv("MDD_LSTM_DBG", "1")
+    m = _hip().HipModel(geom, sd, precision="bf16x3")
+    got = m.forward(_cuda(x), _cuda(x1), sync_errors=True).cpu().numpy()
+    np.testing.assert_array_equal(got, ref)
+    passes = m.tap("lstm_dbg").view(torch.int64).view(256, 6)[:, 5].cpu().numpy()
+    nbt, steps = (B // 16 + 15) // 16, 420 // 4
+    assert passes.min() >= nbt * (steps - 1) and passes.max() > nbt * (steps - 1), (passes.min(), passes.max(), nbt * (steps - 1))
+    print("B=%d: %.2f panels fetched per (tile, step), 1.00 = no redo" % (B, passes.mean() / (nbt * (steps - 1))))
+
+
 def test_decoders_edge_cases_against_oracle():
     from ctc_attention_mispronunciation_amd.utils.ctcDecoder import GreedyDecoder, BeamDecoder
     i2c = synth.phone_table_41()
