@@ -177,7 +177,7 @@ __global__ __launch_bounds__(256, 2) void conv_fused_kernel(const float *__restr
                                                             const unsigned short *__restrict__ w1h, const unsigned short *__restrict__ w1l,
                                                             const float *__restrict__ sc1, const float *__restrict__ sh1,
                                                             unsigned short *__restrict__ out_hi, unsigned short *__restrict__ out_lo,
-                                                            float *__restrict__ out_f32, int B, int T, int Traw) {
+                                                            float *__restrict__ out_f32, int B, int T, int Traw, int S, int seg) {
     constexpr int F = 243, W1 = 122, W2 = 61, CH = 32, ROW = CH * W2;   // 1952
     constexpr int D0 = F / 3;                                           // raw feature width when x holds unstacked frames
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -219,8 +219,7 @@ __global__ __launch_bounds__(256, 2) void conv_fused_kernel(const float *__restr
     // row's elements are requested before this row's arithmetic starts and parked in registers (a row is otherwise a
     // chain global load -> LDS -> conv0 -> conv1 with the ~1 us load latency exposed every time).
     constexpr int XPT = (5 * CF_XLD + 255) / 256;
-    auto load_x = [&](int rowid, float (&dst)[XPT]) {
-        const int tp = rowid / B, b = rowid - tp * B;
+    auto load_x = [&](int tp, int b, float (&dst)[XPT]) {
 #pragma unroll
         for (int k = 0; k < XPT; k++) {
             const int i = tid + 256 * k, r = i / CF_XLD, c = i - r * CF_XLD - 1, ti = 2 * tp - 2 + r;
@@ -237,22 +236,31 @@ __global__ __launch_bounds__(256, 2) void conv_fused_kernel(const float *__restr
             dst[k] = v;
         }
     };
+    // A workgroup walks consecutive output rows tp of ONE utterance (segment sidx of S per utterance): conv0 row 2tp+1 of
+    // one output row is conv0 row 2(tp+1)-1 of the next, so after the first row of a segment only two of the three conv0
+    // rows are computed; the tile's three row slots rotate (logical row r lives in slot (r + rot) % 3).
     float xnext[XPT];
-    if ((int)blockIdx.x < Tp * B) load_x(blockIdx.x, xnext);
-    for (int rowid = blockIdx.x; rowid < Tp * B; rowid += gridDim.x) {
-        const int tp = rowid / B, b = rowid - tp * B;
+    const int b = blockIdx.x / S, sidx = blockIdx.x - b * S;
+    const int tp_begin = sidx * seg, tp_end = min(Tp, tp_begin + seg);
+    if (tp_begin < tp_end) load_x(tp_begin, b, xnext);
+    int rot = 0;
+    for (int tp = tp_begin; tp < tp_end; tp++) {
+        const int rowid = tp * B + b;
+        const bool fresh = tp == tp_begin;
+        if (!fresh) rot = rot == 0 ? 2 : rot - 1;                                  // (rot + 2) % 3: old logical row 2 becomes row 0
         __syncthreads();                                                           // previous row's LDS fully consumed
 #pragma unroll
         for (int k = 0; k < XPT; k++) if (tid + 256 * k < 5 * CF_XLD) xs[tid + 256 * k] = xnext[k];
-        if (rowid + (int)gridDim.x < Tp * B) load_x(rowid + gridDim.x, xnext);
+        if (tp + 1 < tp_end) load_x(tp + 1, b, xnext);   // (all five x rows: skipping the one that only feeds the reused conv0 row costs more in branches than it saves)
         __syncthreads();
         // ---- conv0 on the matrix cores: D[ch, pos] = W0[ch, k] . P[k, pos], k = 9 taps padded to 16 (one MFMA k-step),
         // bf16x3.  A = weights (resident fragments), B = the 3x3 patch of each of the 3*122 = 366 positions (12 tiles of
         // 32, 3 per wave), built from the fp32 x tile.  D puts the position on the lane and 16 channels in the registers
         // (4 groups of 4 consecutive channels), exactly the [r][wcol+1][ci] rows conv1 reads: 8-byte LDS stores.
-        for (int pt = wave; pt < 12; pt += 4) {
-            const int p = pt * 32 + li, pc = min(p, 3 * W1 - 1);
+        for (int pt = wave; pt < (fresh ? 12 : 8); pt += 4) {
+            const int p = (fresh ? 0 : W1) + pt * 32 + li, pc = min(p, 3 * W1 - 1);
             const int r = pc / W1, wc = pc - r * W1, ti = 2 * tp - 1 + r;
+            const int rs = r + rot >= 3 ? r + rot - 3 : r + rot;                   // row slot in the tile
             const bool rowok = ti >= 0 && ti < T && p < 3 * W1;
             float v[8];
 #pragma unroll
@@ -270,7 +278,7 @@ __global__ __launch_bounds__(256, 2) void conv_fused_kernel(const float *__restr
             d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0l, bh, d, 0, 0, 0);
             d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0h, bh, d, 0, 0, 0);
             if (p < 3 * W1) {
-                unsigned char *dh = yh + (r * CF_NCOL + wc + 1) * CF_COLB, *dl = yl + (r * CF_NCOL + wc + 1) * CF_COLB;
+                unsigned char *dh = yh + (rs * CF_NCOL + wc + 1) * CF_COLB, *dl = yl + (rs * CF_NCOL + wc + 1) * CF_COLB;
 #pragma unroll
                 for (int g = 0; g < 4; g++) {      // registers 4g..4g+3 = channels 8g + 4*half + 0..3
                     unsigned short hb[4], lb[4];
@@ -296,7 +304,8 @@ __global__ __launch_bounds__(256, 2) void conv_fused_kernel(const float *__restr
 #pragma unroll
         for (int i = 0; i < 9; i++) {
             const int kb = kh2 * 9 + i, kk = kb >> 1, kh = kk / 3, kw = kk - kh * 3;
-            const int off = (kh * CF_NCOL + 2 * m + kw) * CF_COLB + ((kb & 1) * 16 + half * 8) * 2;   // col index = (2m+kw-1)+1
+            const int khs = kh + rot >= 3 ? kh + rot - 3 : kh + rot;
+            const int off = (khs * CF_NCOL + 2 * m + kw) * CF_COLB + ((kb & 1) * 16 + half * 8) * 2;   // col index = (2m+kw-1)+1
             const bf16x8 ah = *reinterpret_cast<const bf16x8 *>(yh + off);
             const bf16x8 al = *reinterpret_cast<const bf16x8 *>(yl + off);
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bwl[i], acc, 0, 0, 0);
@@ -347,10 +356,15 @@ size_t conv_fused_smem() { return 5 * CF_XLD * 4 + 2 * (size_t)CF_YPLANE + 2048 
 
 int launch_conv_fused(const float *x, const float *w0, const float *sc0, const float *sh0, SplitPtr w1, const float *sc1,
                       const float *sh1, SplitPtr out, float *out_f32, int B, int T, int Traw, hipStream_t st) {
-    const int rows = (T / 2) * B;
-    int grid = rows < 2048 ? rows : 2048;
-    hipLaunchKernelGGL(conv_fused_kernel, dim3(grid), dim3(256), conv_fused_smem(), st, x, w0, sc0, sh0, w1.hi, w1.lo, sc1, sh1,
-                       out.hi, out.lo, out_f32, B, T, Traw);
+    // segments of consecutive output rows per utterance: about 1024 workgroups (two rounds of the 512 that fit the chip)
+    const int Tp = T / 2;
+    if (Tp <= 0 || B <= 0) return MDD_OK;
+    int S = (1024 + B - 1) / B;
+    S = S < 1 ? 1 : (S > Tp ? Tp : S);
+    const int seg = (Tp + S - 1) / S;
+    S = (Tp + seg - 1) / seg;                                                      // no empty segments
+    hipLaunchKernelGGL(conv_fused_kernel, dim3(B * S), dim3(256), conv_fused_smem(), st, x, w0, sc0, sh0, w1.hi, w1.lo, sc1, sh1,
+                       out.hi, out.lo, out_f32, B, T, Traw, S, seg);
     MDD_LAUNCH_CHECK();
     return MDD_OK;
 }
