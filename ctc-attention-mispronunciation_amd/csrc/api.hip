@@ -716,6 +716,20 @@ extern "C" int mdd_align(const int32_t *a, int32_t na, const int32_t *b, int32_t
     return MDD_OK;
 }
 
+extern "C" int mdd_align_batch(const int32_t *a, const int32_t *a_len, int32_t a_stride, const int32_t *b, const int32_t *b_len,
+                               int32_t b_stride, int32_t n, int32_t *dist, uint8_t *ops, int32_t ops_stride, int32_t *nops) {
+    if (n < 0 || a_stride < 0 || b_stride < 0 || ops_stride < 0 || (n > 0 && (!a || !a_len || !b || !b_len || !dist || !ops || !nops))) {
+        set_error("mdd_align_batch: bad argument"); return MDD_ERR_ARG;
+    }
+    for (int x = 0; x < n; x++) {
+        const int na = a_len[x], nb = b_len[x];
+        if (na < 0 || nb < 0 || na > a_stride || nb > b_stride || na + nb > ops_stride) { set_error("mdd_align_batch: row %d does not fit its pitch", x); return MDD_ERR_ARG; }
+        if (na == 0 || nb == 0) { dist[x] = -1; nops[x] = 0; continue; }
+        if (int rc = mdd_align(a + (size_t)x * a_stride, na, b + (size_t)x * b_stride, nb, dist + x, ops + (size_t)x * ops_stride, nops + x)) return rc;
+    }
+    return MDD_OK;
+}
+
 // SURVEY 8(f) #2 -- the evaluation counts of steps/test_ctc_nosil.py for a whole batch, host side.
 // Per utterance (ids already without 'sil'): lc = wer(labels, canonical), dc = wer(decoded, canonical),
 // err = wer(decoded, labels)[0]; d1 / d2 = print_align_space_canonical_origin of the two paths (:33-60): one value

@@ -113,6 +113,23 @@ def align_ids(pair):
     return dist.value, [_OPS[o] for o in ops[:nops.value]]
 
 
+def align_ids_batch(a, a_len, b, b_len):
+    """Edit distance and op path of every row pair of two padded id matrices in one native call (mdd_align_batch).
+
+    a [n, Sa], b [n, Sb] int32 with per-row lengths; returns (dist [n], ops [n, Sa+Sb] uint8 codes 0 '-', 1 'S', 2 'I',
+    3 'D', nops [n]).  A row with an empty side has dist -1 and no ops (the reference's ``wer`` raises there)."""
+    a = np.ascontiguousarray(a, dtype=np.int32); b = np.ascontiguousarray(b, dtype=np.int32)
+    a_len = np.ascontiguousarray(a_len, dtype=np.int32); b_len = np.ascontiguousarray(b_len, dtype=np.int32)
+    if a.ndim != 2 or b.ndim != 2 or a.shape[0] != b.shape[0] or a_len.shape != (a.shape[0],) or b_len.shape != (a.shape[0],):
+        raise ValueError("align_ids_batch: a [n, Sa], b [n, Sb], a_len [n], b_len [n]")
+    n, stride = a.shape[0], a.shape[1] + b.shape[1]
+    dist, nops = np.zeros(n, dtype=np.int32), np.zeros(n, dtype=np.int32)
+    ops = np.zeros((n, max(stride, 1)), dtype=np.uint8)
+    p = lambda v: v.ctypes.data_as(C.c_void_p)
+    _lib.check(_lib.lib().mdd_align_batch(p(a), p(a_len), a.shape[1], p(b), p(b_len), b.shape[1], n, p(dist), p(ops), ops.shape[1], p(nops)))
+    return dist, ops, nops
+
+
 def _device_posteriors(prob_tensor):
     _lib.require_gpu()
     if prob_tensor.dim() != 3:

@@ -142,6 +142,13 @@ int mdd_ctc_loss(const float *logp_dev, int32_t T, int32_t B, int32_t C, const i
  * Either side empty -> MDD_ERR_EMPTY (reference: TypeError). */
 int mdd_align(const int32_t *a, int32_t na, const int32_t *b, int32_t nb, int32_t *dist, uint8_t *ops,
               int32_t *nops);
+/* The same for the n utterances of a batch in one call (the reference loops over the batch calling decoder.wer per
+ * utterance, AA/steps/test_ctc_nosil.py:218-221, AA/infer.py:318-331): row x of a / b (row pitch a_stride / b_stride
+ * ids) with a_len[x] / b_len[x] ids; dist[x], nops[x] and row x of ops (pitch ops_stride >= a_len[x] + b_len[x]).
+ * A row with an empty side gets dist[x] = -1, nops[x] = 0 (the reference's wer raises TypeError for it) and does not
+ * fail the call. */
+int mdd_align_batch(const int32_t *a, const int32_t *a_len, int32_t a_stride, const int32_t *b, const int32_t *b_len,
+                    int32_t b_stride, int32_t n, int32_t *dist, uint8_t *ops, int32_t ops_stride, int32_t *nops);
 
 /* ---- Kaldi-compatible log-mel filterbank + global CMVN (replaces the reference's subprocess pipe
  * `compute-fbank-feats --config=conf/fbank.conf | apply-cmvn --norm-vars=true data/global_fbank_cmvn.txt`,

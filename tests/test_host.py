@@ -35,6 +35,25 @@ def test_alignment_goldens_through_decoder_wer():
     assert dec.cer("kitten", "sitting") == 3
 
 
+def test_alignment_goldens_through_the_batch_entry_point():
+    """mdd_align_batch: the golden pairs (reference wer + printChanges) as one padded batch, empty rows marked -1."""
+    from ctc_attention_mispronunciation_amd.utils.ctcDecoder import align_ids_batch, _tokens_to_ids
+    pairs = jload("g4_align.json")["pairs"]
+    rows = [_tokens_to_ids(r["hyp"], r["can"]) for r in pairs] + [([], [1, 2]), ([3], [])]
+    sa, sb = max(len(a) for a, _ in rows), max(len(b) for _, b in rows)
+    A, Bm = np.full((len(rows), sa), -7, dtype=np.int32), np.full((len(rows), sb), -9, dtype=np.int32)   # padding never read
+    for x, (a, b) in enumerate(rows):
+        A[x, :len(a)] = a; Bm[x, :len(b)] = b
+    dist, ops, nops = align_ids_batch(A, [len(a) for a, _ in rows], Bm, [len(b) for _, b in rows])
+    for x, r in enumerate(pairs):
+        assert dist[x] == r["dist"] and ["-SID"[o] for o in ops[x, :nops[x]]] == r["ops"], r
+    assert list(dist[-2:]) == [-1, -1] and list(nops[-2:]) == [0, 0]
+    d0, o0, n0 = align_ids_batch(np.zeros((0, 3), np.int32), [], np.zeros((0, 2), np.int32), [])
+    assert d0.shape == (0,) and n0.shape == (0,)
+    with pytest.raises(ValueError):
+        align_ids_batch(A, [1], Bm, [1])
+
+
 def test_diagnosis_goldens():
     from ctc_attention_mispronunciation_amd import infer_core as ic
     for r in jload("g4_align.json")["pairs"]:
