@@ -155,7 +155,28 @@ __global__ __launch_bounds__(256, 2) void attn_tail_mfma_kernel(const float *__r
     const float *xsrc = X + ((size_t)xrow * B + b) * H2 + wave * (D2 / 4) + 4 * kq;   // + 16 j
     const float *scp = fscale + wave * (D2 / 4) + 4 * kq, *shp = fshift + wave * (D2 / 4) + 4 * kq;
 
-    // 1. softmax over L (one wave per row); padded rows / columns are zero
+    // 1. softmax over L (one wave per row); padded rows / columns are zero.  With L <= 64 (one element per lane) a wave's
+    //    four rows are requested together: four dependent global round trips become one.
+    if (L <= 64) {
+        float sv[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int r = wave + 4 * i;
+            sv[i] = (r < nt_rows && lane < L) ? S[((size_t)b * Tp + t0 + r) * Lp + lane] : -INFINITY;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int r = wave + 4 * i;
+            float *arow = attw + r * LA;
+            if (r >= nt_rows) { if (lane < LA) arow[lane] = 0.f; continue; }
+            float mx = sv[i];
+            for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+            const float e = lane < L ? expf(sv[i] - mx) : 0.f;
+            float sum = e;
+            for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+            if (lane < LA) arow[lane] = lane < L ? e / sum : 0.f;
+        }
+    } else
     for (int r = wave; r < 16; r += 4) {
         float *arow = attw + r * LA;
         if (r >= nt_rows) { for (int l = lane; l < LA; l += 64) arow[l] = 0.f; continue; }
