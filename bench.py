@@ -39,13 +39,17 @@ def parse():
     ap.add_argument("--warmup", type=int, default=32)
     ap.add_argument("--workload", default="joint64", choices=["joint64", "greedy32"])
     ap.add_argument("--hidden", type=int, default=384)
-    ap.add_argument("--lanes", type=int, default=1, help="independent stream pipelines per GPU")
+    ap.add_argument("--lanes", type=int, default=1, help="(must be 1) independent stream pipelines per GPU: two forwards in flight on one "
+                    "device would put two persistent BiLSTM launches side by side, each waiting for CUs the other holds")
     ap.add_argument("--fuse", type=int, default=8, help="reference-sized batches carried by one launch sequence")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true", help="skip the posterior all-gather at N>1")
     ap.add_argument("--decoder", default=None, choices=[None, "beam", "greedy", "none"], help="diagnostic override of the decode stage")
     ap.add_argument("--no-roofline", action="store_true", help="skip the stage-replay pass (for clean traces)")
-    return ap.parse_args()
+    args = ap.parse_args()
+    if args.lanes != 1:
+        ap.error("--lanes must be 1: a persistent BiLSTM layer needs every CU of the device; batch more work per pass with --fuse instead")
+    return args
 
 
 def main():
