@@ -797,7 +797,8 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_granule_kernel(PersistArgs 
                         // each accumulator still sees ah.bl, al.bh, ah.bh in that order (bit-identical to the step kernel)
                         // (the scheduler would otherwise regroup them per accumulator into dependent back-to-back pairs)
 #pragma unroll
-                        for (int rt = 0; rt < RTW; rt++) acc[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[rt][ks], bl, acc[rt], 0, 0, 0);
+                        for (int rt = 0; rt < RTW; rt++)   // the first product of a tile starts from a literal zero: no accumulator clearing per phase (or per redo)
+                            acc[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[rt][ks], bl, ks == 0 ? (f32x4){0.f, 0.f, 0.f, 0.f} : acc[rt], 0, 0, 0);
                         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                         for (int rt = 0; rt < RTW; rt++) mfma_a(acc[rt], al[rt][ks], bh);   // lo fragments stay in AGPRs and feed the MFMA from there
@@ -820,8 +821,6 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_granule_kernel(PersistArgs 
                     request_sweep(bt, s, pb);
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     lds_barrier();
-#pragma unroll
-                    for (int rt = 0; rt < RTW; rt++) acc[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
                 }
                 if (a.dbg && PF != 0) ph[5] += 1;
                 const long long tpl = a.dbg ? (long long)__builtin_readcyclecounter() : 0;
