@@ -713,7 +713,7 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_granule_kernel(PersistArgs 
                 const int pb = pc & 1;
                 ++pc;
                 const unsigned ep = (unsigned)((s - 1) % 3 + 1), etag = (ep & 1u) | ((ep >> 1) << 16);   // tag of step s-1: bit 0 in lo0, bit 1 in lo1
-                const long long t0 = wall_clock64();
+                long long t0 = 0;   // wall clock at the first retry (read lazily: its scalar load would sit in front of every phase's first barrier)
                 // ---- the tile's panel of step s-1 -> LDS
                 if (PF == 0) {
                     // one tile: nothing to overlap.  Each wave polls its own pieces (read back through LDS) until all tags match.
@@ -732,6 +732,7 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_granule_kernel(PersistArgs 
                         if (!__any((bad & 0x00010001u) != 0)) break;
                         if ((polls & 63) == 0) {
                             int ab = 0;
+                            if (t0 == 0) t0 = wall_clock64();
                             if (lane == 0) ab = (__hip_atomic_load(abortf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) || (wall_clock64() - t0 > 200000000ll);
                             if (__any(ab)) {
                                 if (lane == 0) { __hip_atomic_store(abortf, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); atomicExch(a.err_flag, 2); s_fail = 1; }
@@ -745,7 +746,9 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_granule_kernel(PersistArgs 
                 } else {
                     // requested a phase ago (or just now: the first step after s = 0)
                     if (!requested) { request_sweep(bt, s, pb); younger = 0; }
+                    const long long tw = a.dbg ? (long long)__builtin_readcyclecounter() : 0;
                     wait_vmcnt(younger);
+                    if (a.dbg) ph[1] += (long long)__builtin_readcyclecounter() - tw;
                 }
                 requested = false;
                 lds_barrier();                                          // every wave's pieces of the panel are in LDS
@@ -813,6 +816,7 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_granule_kernel(PersistArgs 
                     // ---- stale panel (identical verdict in every wave): fetch it again, redo the products
                     ++tries;
                     if (a.dbg) ph[5] += 1;
+                    if (t0 == 0) t0 = wall_clock64();
                     if (lane == 0 && ((__hip_atomic_load(abortf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) || (wall_clock64() - t0 > 200000000ll))) {
                         __hip_atomic_store(abortf, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); atomicExch(a.err_flag, 2); s_fail = 1;
                     }
@@ -823,7 +827,6 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_granule_kernel(PersistArgs 
                     lds_barrier();
                 }
                 if (a.dbg && PF != 0) ph[5] += 1;
-                const long long tpl = a.dbg ? (long long)__builtin_readcyclecounter() : 0;
                 if (do_rq) requested = true;
                 int in_flight = tries ? 0 : ((do_gx ? NGX : 0) + ((do_rq || early) ? NLD : 0));
                 early_gx = (early && do_gx && !tries) ? NGX : 0;       // memory instructions younger than an early request
@@ -832,7 +835,6 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_granule_kernel(PersistArgs 
                     in_flight += NLD;
                 }
                 wait_vmcnt(in_flight);   // everything older than this phase's pieces has landed: in particular this tile's current gx slab
-                if (a.dbg) ph[1] += (long long)__builtin_readcyclecounter() - tpl;
                 lds_barrier();   // every wave is done with the LDS panel; every wave's part of the gx slab is in LDS
             }
             if (s == 0 && T > 1) load_gx(bt, 1, d ? (T - 2) : 1);

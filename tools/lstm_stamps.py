@@ -15,7 +15,7 @@ for B in [int(v) for v in (sys.argv[1:] or ['64', '256'])]:
     for _ in range(2): m.forward(x, x1)
     torch.cuda.synchronize()
     ph = m.tap('lstm_dbg').view(torch.int64).view(256, 6).cpu().numpy().astype(np.float64)
-    names = ['wait team', '(of MFMA: request + counted wait)', 'MFMA', 'cell+publish', 'output stores', '-']
+    names = ['wait team', '(of which: the counted vmcnt wait)', 'MFMA', 'cell+publish', 'output stores', '-']
     tot = ph[:, [0, 2, 3, 4]].sum(1)
     print('B=%d  cycles per step (mean over WGs / max WG):' % B)
     for i in range(5):
