@@ -251,7 +251,7 @@ def test_forward_edge_shapes_against_oracle(B, T, L, precision):
     np.testing.assert_allclose(got, oracle.forward(sd, x, x1), rtol=0, atol=TOL)
 
 
-@pytest.mark.parametrize("B", [100, 256, 300, 512, 700, 1000])
+@pytest.mark.parametrize("B", [17, 100, 256, 300, 512, 513, 700, 1000, 1024])
 def test_persistent_lstm_batch_sizes_match_step_kernels(B, monkeypatch):
     """Every team geometry of the persistent BiLSTM (1 to 4 row tiles per team in the granule form, and the counter
     form) against the per-step split-bf16 kernels, bit for bit; short sequence, full width."""
