@@ -618,63 +618,61 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_granule_kernel(PersistArgs 
     unsigned int *abortf = a.sync + 16;
     long long ph[6] = {0, 0, 0, 0, 0, 0}, tst = a.dbg ? (long long)__builtin_readcyclecounter() : 0;
 
-    // gate pre-activations of (tile bt, time tt) -> Gx[bt]: each wave-instruction lands 1 KB lane-linear in LDS; the
-    // workgroup's slice of a gx row is one contiguous run of 4*UW floats (gate columns are unit-major)
-    // (slot = (unit + row) mod UW inside a row: the 16 lanes that read one unit of 16 rows then hit 16 different bank groups)
-    constexpr int NGX = 16 * UW / NTH;                              // 1 KB wave loads per slab and wave
-    int grow[4], gcol[4];                                           // (literal bound: a dependent one breaks the host-side instantiation)
-    static_assert(NGX <= 4, "slab chunk table");                                       // slab chunk i of this thread: row, float offset of its unit in a gx row
-#pragma unroll
-    for (int i = 0; i < NGX; i++) {
-        const int e = i * NTH + tid, r = e / UW, slot = e - r * UW, c = slot - r < 0 ? slot - r + UW : slot - r;
-        grow[i] = r; gcol[i] = (d * 4 * H) + (member * UW + c) * 4;
-    }
+    // gate pre-activations of (tile bt, time tt) -> Gx[bt]: one LDS-DMA piece per row tile of the wave, and lane (row li,
+    // unit kq) of piece rt fetches exactly the 16 bytes (i, f, g, o of its unit and row) that the same lane consumes in
+    // the cell update of row tile rt: nothing crosses waves, so no barrier stands between the transfer and its use
+    constexpr int NGX = RTW;                                        // 1 KB wave loads per slab and wave
+    const unsigned gvoff = (unsigned)(d * 4 * H + (member * UW + wave * RTW * 4 + kq) * 4) * 4u;   // byte offset of row tile 0's unit in a gx row
     const unsigned wave_lds = __builtin_amdgcn_readfirstlane((unsigned)wave * 1024u);   // a wave's 1 KB slot inside a 4 KB LDS-DMA pass
+    const unsigned wave_gx = __builtin_amdgcn_readfirstlane((unsigned)wave * (unsigned)(RTW * 1024));   // a wave's RTW row tiles inside a slab
     const unsigned gx_lds = (unsigned)(unsigned long long)(lds_void_t *)Gx, rw_lds = (unsigned)(unsigned long long)(lds_void_t *)Rw;
     auto load_gx = [&](int bt, int par, int tt, int i0 = 0, int i1 = 99) {
         i1 = i1 > NGX ? NGX : i1;
         const float *gbase = a.gx + (size_t)tt * B * 2 * 4 * H;
+        const int b = min(g * a.BGr + min(bt * 16 + li, a.BGr - 1), B - 1);           // rows past the batch read a valid row (never used)
+        const unsigned rowoff = (unsigned)b * (unsigned)(2 * 4 * H * 4) + gvoff;
 #pragma unroll
-        for (int i = i0; i < i1; i++) {
-            const int b = min(g * a.BGr + min(bt * 16 + grow[i], a.BGr - 1), B - 1);     // rows past the batch read a valid row (never used)
-            lds_dma16_s<false>(gbase, (unsigned)(b * 2 * 4 * H + gcol[i]) * 4u, gx_lds + (unsigned)(((bt * 2 + par) * GXT + i * NTH * 4) * 4) + wave_lds);
-        }
+        for (int i = i0; i < i1; i++)
+            lds_dma16_s<false>(gbase, rowoff + (unsigned)(i * 64), gx_lds + (unsigned)(((bt * 2 + par) * GXT + i * 256) * 4) + wave_gx);
     };
-    // Layer outputs and the publish leave as whole 16-byte chunks read back from the LDS tiles.  Every wave issues exactly
-    // one buffer store per destination (lanes without a chunk, and nothing else, are dropped by the buffer range check;
-    // lanes of rows past the batch repeat the tile's last valid row: identical bytes to the same address), so that the
-    // number of memory operations a wave issues after a sweep request is known exactly -- see the counted wait below.
-    // The LDS reads of a phase are issued together, ahead of the stores (one LDS round trip, not one per store).
-    constexpr int CH = UW / 8, CF = UW / 4;                           // 16-byte chunks per row: bf16 planes, fp32
-    constexpr int PWS = 2 * 16 * CH / 4, PWR = 16 * CF / 4, PWP = 16 * (UW / 4) / 4;   // chunks per wave: split planes (both), fp32, publish
-    static_assert((16 * CH) % PWS == 0 || PWS % (16 * CH) == 0, "a wave's split-plane chunks belong to one plane");
-    const int qs = wave * PWS + lane, pls = __builtin_amdgcn_readfirstlane(wave * PWS >= 16 * CH), qqs = qs - pls * 16 * CH, rs = qqs / CH, cs = qqs % CH;
-    const int qr = wave * PWR + lane, rr = qr / CF, cr = qr % CF;
+    // Layer outputs and the publish are read back from the LDS tiles as 16- or 8-byte pieces and leave as buffer stores.
+    // Every wave stores exactly the units it produced (its RTW row tiles = 4*RTW consecutive units of all 16 rows): the
+    // tiles never cross waves, so no barrier stands between the cell update and the stores either.  Every wave issues a
+    // fixed number of store instructions per destination (lanes without a piece, and nothing else, are dropped by the
+    // buffer range check; lanes of rows past the batch repeat the tile's last valid row: identical bytes to the same
+    // address), so that the number of memory operations a wave issues after a sweep request is known exactly -- see
+    // the counted wait below.  The LDS reads of a phase are issued together, ahead of the stores.
+    constexpr int UWW = UW / 4, PCW = UWW / 4;                          // units per wave; 4-unit pieces per row (16 B of fp32, 8 B of a bf16 plane)
+    constexpr int PWR = 16 * PCW, PWP = 16 * (UW / 4) / 4;               // pieces per wave: layer outputs (per destination), publish chunks
+    static_assert(UWW % 4 == 0 && PWR <= 64 && PWP == 16 * RTW, "a wave's output pieces fit one instruction; it publishes its own row tiles");
+    const int orow = lane / PCW, ocol = wave * UWW + (lane - orow * PCW) * 4;   // output role of this lane: tile row, first of its 4 units
     const int qp = min(wave * PWP + lane, 16 * (UW / 4) - 1);
     const unsigned offp = lane < PWP ? (unsigned)(member * 16 * (UW / 4) + wave * PWP + lane) * 16u : 0xffffffffu;
     const size_t slab = (size_t)B * 2 * H;                              // elements of one time step of the layer output
     auto tile_rows = [&](int bt) { const int nv = min(a.BGr, B - g * a.BGr) - bt * 16; return nv < 0 ? 0 : (nv > 16 ? 16 : nv); };
-    struct OutRegs { u32x4 vs, vr; int r1, r2; };
+    struct OutRegs { u32x2 vh, vl; u32x4 vr; int r; };
     auto out_read = [&](int bt, OutRegs &o) {
-        const int nv = max(tile_rows(bt), 1);
-        o.r1 = min(rs, nv - 1); o.r2 = min(rr, nv - 1);
-        if (a.out_split.hi) o.vs = *reinterpret_cast<const u32x4 *>((pls ? Ol : Oh) + o.r1 * UW + cs * 8);
-        if (a.out_raw) o.vr = *reinterpret_cast<const u32x4 *>(Of + o.r2 * UW + cr * 4);
+        o.r = min(orow, max(tile_rows(bt), 1) - 1);
+        if (a.out_split.hi) {
+            o.vh = *reinterpret_cast<const u32x2 *>(Oh + o.r * UW + ocol);
+            o.vl = *reinterpret_cast<const u32x2 *>(Ol + o.r * UW + ocol);
+        }
+        if (a.out_raw) o.vr = *reinterpret_cast<const u32x4 *>(Of + o.r * UW + ocol);
     };
     auto out_write = [&](int bt, int tt, const OutRegs &o) -> int {
         if (tile_rows(bt) == 0) return 0;
         int issued = 0;
-        const int b0 = g * a.BGr + bt * 16;
+        const unsigned el = lane < PWR ? (unsigned)((g * a.BGr + bt * 16 + o.r) * 2 * H + d * H + member * UW + ocol) : 0x3fffffffu;   // element offset in the step's slab (out of range: dropped)
         if (a.out_split.hi) {
-            const __amdgpu_buffer_rsrc_t rs_ = __builtin_amdgcn_make_buffer_rsrc((pls ? a.out_split.lo : a.out_split.hi) + (size_t)tt * slab, 0, (int)(slab * 2), 0x00020000);
-            const unsigned off = lane < PWS ? (unsigned)((b0 + o.r1) * 2 * H + d * H + member * UW + cs * 8) * 2u : 0xffffffffu;
-            __builtin_amdgcn_raw_buffer_store_b128(o.vs, rs_, off, 0, 0);
-            issued++;
+            const __amdgpu_buffer_rsrc_t rh = __builtin_amdgcn_make_buffer_rsrc(a.out_split.hi + (size_t)tt * slab, 0, (int)(slab * 2), 0x00020000);
+            const __amdgpu_buffer_rsrc_t rl = __builtin_amdgcn_make_buffer_rsrc(a.out_split.lo + (size_t)tt * slab, 0, (int)(slab * 2), 0x00020000);
+            __builtin_amdgcn_raw_buffer_store_b64(o.vh, rh, el * 2u, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b64(o.vl, rl, el * 2u, 0, 0);
+            issued += 2;
         }
         if (a.out_raw) {
             const __amdgpu_buffer_rsrc_t rs_ = __builtin_amdgcn_make_buffer_rsrc(a.out_raw + (size_t)tt * slab, 0, (int)(slab * 4), 0x00020000);
-            const unsigned off = lane < PWR ? (unsigned)((b0 + o.r2) * 2 * H + d * H + member * UW + cr * 4) * 4u : 0xffffffffu;
-            __builtin_amdgcn_raw_buffer_store_b128(o.vr, rs_, off, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(o.vr, rs_, el * 4u, 0, 0);
             issued++;
         }
         return issued;
@@ -834,8 +832,7 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_granule_kernel(PersistArgs 
                     request_sweep(nbt, ns, pb ^ 1); requested = true;
                     in_flight += NLD;
                 }
-                wait_vmcnt(in_flight);   // everything older than this phase's pieces has landed: in particular this tile's current gx slab
-                lds_barrier();   // every wave is done with the LDS panel; every wave's part of the gx slab is in LDS
+                wait_vmcnt(in_flight);   // everything older than this phase's pieces has landed: in particular this wave's part of the tile's current gx slab
             }
             if (s == 0 && T > 1) load_gx(bt, 1, d ? (T - 2) : 1);
             PSTAMP(2);
@@ -846,11 +843,8 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_granule_kernel(PersistArgs 
             float4 gv[RTW];
             float hn[RTW];
 #pragma unroll
-            for (int rt = 0; rt < RTW; rt++) {   // the three slab reads together: one LDS round trip
-                const int ul = (wave * RTW + rt) * 4 + kq;
-                const int gslot = ul + li >= UW ? ul + li - UW : ul + li;
-                gv[rt] = *reinterpret_cast<const float4 *>(Gx + (bt * 2 + (s & 1)) * GXT + (li * UW + gslot) * 4);
-            }
+            for (int rt = 0; rt < RTW; rt++)     // the slab reads together (one LDS round trip), each lane its own 16 bytes
+                gv[rt] = *reinterpret_cast<const float4 *>(Gx + (bt * 2 + (s & 1)) * GXT + ((wave * RTW + rt) * 64 + lane) * 4);
 #pragma unroll
             for (int rt = 0; rt < RTW; rt++) {   // branch-free: the row tiles' chains interleave
                 const float ig = fast_sigmoid(acc[rt][0] + gv[rt].x), fg = fast_sigmoid(acc[rt][1] + gv[rt].y);
@@ -874,7 +868,6 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_granule_kernel(PersistArgs 
                 ogp[4] = (unsigned short)((hw >> 16) | ((kq & 1) ? (tg >> 1) : (tg & 1u)));
             }
             PSTAMP(3);
-            lds_barrier();                                         // the tiles are complete; the gx slab is consumed
             // ---- publish h_s (no drain, no signal): the workgroup's share of the tile's panel is one contiguous run of
             // 16 * UW / 4 chunks, written as 16-byte write-through stores straight from the Og tile (same order)
             younger = early_gx; early_gx = 0;
