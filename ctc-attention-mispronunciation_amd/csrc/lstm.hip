@@ -861,7 +861,7 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_granule_kernel(PersistArgs 
                 __bf16 ob = (__bf16)ov, ol = (__bf16)(ov - (float)ob);
                 Oh[li * UW + ul] = *reinterpret_cast<unsigned short *>(&ob);
                 Ol[li * UW + ul] = *reinterpret_cast<unsigned short *>(&ol);
-                Of[li * UW + ul] = hn[rt];
+                if (a.out_raw) Of[li * UW + ul] = hn[rt];
                 const unsigned hw = split_h(hn[rt]);                   // chunk = {hi0 hi1 hi2 hi3 | lo0' lo1' lo2' lo3'}: tag bit 0 rides in the even units' lo, bit 1 in the odd units'
                 unsigned short *ogp = reinterpret_cast<unsigned short *>(Og) + (cl * 16 + li) * 8 + kq;
                 ogp[0] = (unsigned short)(hw & 0xffffu);
