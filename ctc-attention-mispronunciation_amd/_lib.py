@@ -16,6 +16,7 @@ EXPORTS = (
     "mdd_last_error", "mdd_version", "mdd_create", "mdd_destroy", "mdd_load_weight", "mdd_finalize_weights",
     "mdd_set_precision", "mdd_get_precision", "mdd_stack_len", "mdd_stack_skip", "mdd_len_frames", "mdd_forward", "mdd_forward_raw", "mdd_forward_num_stages", "mdd_forward_profile", "mdd_tap", "mdd_tap_copy", "mdd_enable_taps", "mdd_sync",
     "mdd_greedy", "mdd_beam", "mdd_ctc_loss", "mdd_align", "mdd_align_batch", "mdd_eval_batch", "mdd_fbank_num_frames", "mdd_fbank",
+    "mdd_diag_gemm", "mdd_diag_gemm_ph8",
 )
 
 

@@ -5,6 +5,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <mutex>
 #include <vector>
 
 #include "mdd_internal.h"
@@ -19,6 +20,20 @@ void set_error(const char *fmt, ...) {
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
 }
+
+// Per-device gate for forwards that contain persistent BiLSTM launches.  A persistent layer kernel needs all of its
+// 256 workgroups resident (one per CU); two of them in flight on one device -- two handles, two host threads, two
+// streams -- would each hold CUs the other is waiting for until the wall-clock abort.  So every such forward is
+// ordered behind the previous one on the same device: the new stream waits for an event recorded at the end of the
+// previous forward (a device-side dependency, the host never blocks).  Process-wide; one process per device is the
+// deployment model (a second PROCESS on the same device is outside this gate: use MDD_LSTM=step there).
+struct DeviceGate {
+    std::mutex mu;
+    hipEvent_t done = nullptr;        // recorded behind the last gated forward
+    hipStream_t stream = nullptr;     // the stream it was recorded on
+    bool armed = false;
+};
+static DeviceGate g_gate[64];
 
 struct DevBuf {
     float *p = nullptr;
@@ -69,7 +84,7 @@ struct mdd_model {
     unsigned int *sync_words = nullptr;
     bool lstm_x3 = false;   // MDD_LSTM=x3: LDS-tiled split-bf16 step kernel (measured slower than the packed fp32 step; kept for study)
     bool conv_fused() const { return x3() && cfg.feat == 243 && cfg.channels == 32; }
-    bool persist(int B) const { return x3() && lstm_persist && !lstm_x3 && n_cu >= 256 && B <= (lstm_granule ? granule_max_b : 512); }
+    bool persist(int B) const { return x3() && lstm_persist && !lstm_x3 && B <= (lstm_granule ? granule_max_b : 512); }
     bool x3() const {   // the bf16x3 GEMM needs K % 32 == 0 for every contraction and the packed LSTM layouts
         return precision == 1 && (cfg.hidden == 384 || cfg.hidden == 256) && rnn_in() % 32 == 0 && cfg.emb_dim % 32 == 0;
     }
@@ -275,6 +290,33 @@ static int run_stage(mdd_model *m, int si, const float *x, int B, int T, const i
     }
 }
 
+// Enter / leave the device gate around the enqueue of one forward on `st` (no-op while `st` is being captured by the
+// caller: the captured graph then carries the caller's own ordering).
+static int gate_enter(mdd_model *m, hipStream_t st, bool *held) {
+    *held = false;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (st && hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) return MDD_OK;
+    DeviceGate &g = g_gate[m->device & 63];
+    g.mu.lock();
+    *held = true;
+    if (g.armed && g.stream != st) {
+        hipError_t e = hipStreamWaitEvent(st, g.done, 0);
+        if (e != hipSuccess) { g.mu.unlock(); *held = false; set_error("device gate: %s", hipGetErrorString(e)); return MDD_ERR_HIP; }
+    }
+    return MDD_OK;
+}
+static int gate_leave(mdd_model *m, hipStream_t st, bool held, int rc) {
+    if (!held) return rc;
+    DeviceGate &g = g_gate[m->device & 63];
+    hipError_t e = hipSuccess;
+    if (!g.done) e = hipEventCreateWithFlags(&g.done, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventRecord(g.done, st);
+    if (e == hipSuccess) { g.armed = true; g.stream = st; }
+    g.mu.unlock();
+    if (e != hipSuccess && rc == MDD_OK) { set_error("device gate: %s", hipGetErrorString(e)); return MDD_ERR_HIP; }
+    return rc;
+}
+
 static int forward_enqueue(mdd_model *m, const float *x, int B, int T, const int64_t *x1, int L, float *logp, hipStream_t st) {
     for (int si = 0; si < n_stages(m); si++)
         if (int rc = run_stage(m, si, x, B, T, x1, L, logp, st, nullptr)) return rc;
@@ -324,6 +366,7 @@ extern "C" int mdd_create(const mdd_config *cfg, int device, mdd_model **out) {
     if (int rc = init_conv_attributes()) { delete m; return rc; }
     if (int rc = init_gemm_attributes()) { delete m; return rc; }
     m->n_cu = prop.multiProcessorCount;
+    if (!persistent_grid_fits(m->n_cu)) m->lstm_persist = false;   // per-step kernels instead (smaller partitions, other gfx950 SKUs)
     hipError_t e = hipMalloc((void **)&m->err_flag, sizeof(int));
     if (e == hipSuccess) e = hipMemset(m->err_flag, 0, sizeof(int));
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&m->cap_stream, hipStreamNonBlocking);
@@ -534,7 +577,13 @@ extern "C" int mdd_forward(mdd_model *m, const float *x_dev, int32_t B, int32_t 
     int rc = forward_prepare(m, x_dev, B, T, x1_dev, L, logp_dev);
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
-    if (!m->use_graph) return forward_enqueue(m, x_dev, B, T, x1_dev, L, logp_dev, st);
+    const bool gated = m->persist(B);
+    bool held = false;
+    if (!m->use_graph) {
+        if (gated && (rc = gate_enter(m, st, &held))) return rc;
+        rc = forward_enqueue(m, x_dev, B, T, x1_dev, L, logp_dev, st);
+        return gate_leave(m, st, held, rc);
+    }
     GraphKey key;
     memset(&key, 0, sizeof(key));
     key.x = x_dev; key.x1 = x1_dev; key.out = logp_dev; key.B = B; key.T = T; key.L = L; key.Traw = m->raw_T;
@@ -553,8 +602,10 @@ extern "C" int mdd_forward(mdd_model *m, const float *x_dev, int32_t B, int32_t 
         if (e != hipSuccess) { set_error("graph instantiate failed: %s", hipGetErrorString(e)); return MDD_ERR_HIP; }
         it = m->graphs.emplace(key, exec).first;
     }
-    MDD_HIP_CHECK(hipGraphLaunch(it->second, st));
-    return MDD_OK;
+    if (gated && (rc = gate_enter(m, st, &held))) return rc;
+    hipError_t le = hipGraphLaunch(it->second, st);
+    if (le != hipSuccess) { set_error("hipGraphLaunch failed: %s", hipGetErrorString(le)); return gate_leave(m, st, held, MDD_ERR_HIP); }
+    return gate_leave(m, st, held, MDD_OK);
 }
 
 // A1 + forward in one call: raw_dev = unstacked frames [B, T_raw, feat/3].  With the fused conv front-end the stack/skip
@@ -586,6 +637,11 @@ extern "C" int mdd_forward_profile(mdd_model *m, const float *x_dev, int32_t B, 
     const int ns = n_stages(m);
     if (cap < ns || !ms || !launches || !flops || !names) { set_error("mdd_forward_profile: need room for %d stages", ns); return MDD_ERR_ARG; }
     hipStream_t st = (hipStream_t)stream;
+    if (m->persist(B)) {   // keep other handles' forwards off the device while the stages replay: wait for the last gated forward
+        bool held = false;
+        if ((rc = gate_enter(m, st, &held))) return rc;
+        if ((rc = gate_leave(m, st, held, MDD_OK))) return rc;
+    }
     hipEvent_t e0, e1;
     MDD_HIP_CHECK(hipEventCreate(&e0));
     MDD_HIP_CHECK(hipEventCreate(&e1));

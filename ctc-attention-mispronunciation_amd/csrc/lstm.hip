@@ -899,12 +899,14 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_granule_kernel(PersistArgs 
 
 int granule_bg(int B) { const int r = (B + 15) / 16; return (r + 15) / 16 * 16; }   // rows per batch group (16 groups), padded to whole tiles
 
+static constexpr int kPersistGrid = 256;   // see persistent_grid_fits()
+
 template <int H, int NBT, int RTW>
 static int launch_granule_t(PersistArgs a, hipStream_t st) {
     const size_t smem = (size_t)16 * (H / 8) * 12 + (size_t)NBT * 2 * 16 * (H / 8) * 16 + (size_t)2 * 16 * H * 4;   // tiles (2 bf16 planes, fp32, tagged words) + gx slabs (2 parities) + two panel buffers
     MDD_HIP_CHECK(hipMemsetAsync(a.sync, 0, 32 * sizeof(unsigned int), st));
     MDD_HIP_CHECK(hipMemsetAsync(a.hx, 0, (size_t)2 * 32 * NBT * 16 * H * 4, st));   // tags must start at 0 on every launch
-    hipLaunchKernelGGL((lstm_layer_granule_kernel<H, NBT, RTW>), dim3(256), dim3(256), smem, st, a);
+    hipLaunchKernelGGL((lstm_layer_granule_kernel<H, NBT, RTW>), dim3(kPersistGrid), dim3(256), smem, st, a);
     MDD_LAUNCH_CHECK();
     return MDD_OK;
 }
@@ -935,12 +937,27 @@ int init_granule_attributes() {
     return MDD_OK;
 }
 
+// The persistent layer kernels are written for a grid of exactly kPersistGrid workgroups (2 directions x 16 batch
+// groups x 8 team members), ALL resident at once, one per CU.  persistent_grid_fits() asks the runtime whether a device
+// with n_cu compute units can hold that grid (>= 1 workgroup of the largest configuration per CU, and enough CUs); when it
+// cannot, the library uses the per-step kernels instead of risking a grid that waits for workgroups that never start.
+int persistent_grid_fits(int n_cu) {
+    if (n_cu < kPersistGrid) return 0;
+    int per_cu = 0;
+    const size_t smem384 = (size_t)16 * (384 / 8) * 12 + (size_t)4 * 2 * 16 * (384 / 8) * 16 + (size_t)2 * 16 * 384 * 4;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)lstm_layer_granule_kernel<384, 4, 3>, 256, smem384) != hipSuccess) return 0;
+    if (per_cu < 1) return 0;
+    const size_t smem256 = (size_t)16 * (256 / 8) * 12 + (size_t)4 * 2 * 16 * (256 / 8) * 16 + (size_t)2 * 16 * 256 * 4;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)lstm_layer_granule_kernel<256, 4, 2>, 256, smem256) != hipSuccess) return 0;
+    return per_cu >= 1 ? 1 : 0;
+}
+
 template <int H, int NBT>
 static int launch_persistent_t(const PersistArgs &a, hipStream_t st) {
     constexpr int ROWB = H * 2 + 16;
     const size_t smem = (size_t)2 * a.BG * ROWB;
     MDD_HIP_CHECK(hipMemsetAsync(a.sync, 0, 32 * sizeof(unsigned int), st));
-    hipLaunchKernelGGL((lstm_layer_persistent_kernel<H, NBT>), dim3(256), dim3(H / 64 * 64), smem, st, a);
+    hipLaunchKernelGGL((lstm_layer_persistent_kernel<H, NBT>), dim3(kPersistGrid), dim3(H / 64 * 64), smem, st, a);
     MDD_LAUNCH_CHECK();
     return MDD_OK;
 }

@@ -87,6 +87,7 @@ int init_persistent_attributes();
 int persistent_bg(int B);
 int granule_bg(int B);
 int init_granule_attributes();
+int persistent_grid_fits(int n_cu);   // 1 when all 256 workgroups of a persistent layer launch can be resident at once
 // data-tagged variant (8-workgroup teams, no counter): hx = 2*32*granule_bg(B)*H u64 granules (+ stamps), sync: 32 uints
 int launch_lstm_layer_granule(const LstmStepArgs &s, unsigned short *hx, unsigned int *sync, int *err_flag, hipStream_t st);
 int launch_lstm_layer_persistent(const LstmStepArgs &s, unsigned short *hx, unsigned int *sync, int *err_flag, hipStream_t st);

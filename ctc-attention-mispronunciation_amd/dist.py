@@ -22,6 +22,18 @@ def shard_batches(n_batches, rank=None, world_size=None):
     return list(range(rank, n_batches, world_size))
 
 
+def _all_gather_rows(out, src):
+    """out [world * n, ...] <- src [n, ...] of every rank, in rank order.  RCCL ("nccl") gathers device tensors in place
+    on the current stream; gloo (CPU tests, and the N>1 rehearsal on a box with fewer GPUs than ranks) has no device
+    collectives, so device tensors make the round trip through host memory there."""
+    if dist.get_backend() == "gloo" and src.is_cuda:
+        h = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_gather_into_tensor(h, src.contiguous().cpu())
+        out.copy_(h)
+    else:
+        dist.all_gather_into_tensor(out, src.contiguous())
+
+
 def gather_posteriors(logp, out=None):
     """All-gather equal-shape posteriors [T', B, C] of every rank -> [world, T', B, C] (one collective)."""
     _, w = world()
@@ -29,7 +41,7 @@ def gather_posteriors(logp, out=None):
         return logp.unsqueeze(0)
     if out is None:
         out = torch.empty((w,) + tuple(logp.shape), dtype=logp.dtype, device=logp.device)
-    dist.all_gather_into_tensor(out.view((-1,) + tuple(logp.shape[1:])), logp.contiguous())   # concatenated along dim 0
+    _all_gather_rows(out.view((-1,) + tuple(logp.shape[1:])), logp)   # concatenated along dim 0
     return out
 
 
@@ -40,8 +52,8 @@ def gather_decoded(ids, nids):
         return [ids], [nids]
     all_ids = torch.empty((w,) + tuple(ids.shape), dtype=ids.dtype, device=ids.device)
     all_n = torch.empty((w,) + tuple(nids.shape), dtype=nids.dtype, device=nids.device)
-    dist.all_gather_into_tensor(all_ids.view((-1,) + tuple(ids.shape[1:])), ids.contiguous())
-    dist.all_gather_into_tensor(all_n.view(-1), nids.contiguous())
+    _all_gather_rows(all_ids.view((-1,) + tuple(ids.shape[1:])), ids)
+    _all_gather_rows(all_n.view(-1), nids)
     return list(all_ids.unbind(0)), list(all_n.unbind(0))
 
 
@@ -53,16 +65,21 @@ def decode_sharded(batches, decode_fn, pad_len):
     mine = shard_batches(len(batches), rank, w)
     rounds = (len(batches) + w - 1) // w
     results = [None] * len(batches)
-    proto = None
+    first = decode_fn(batches[mine[0]]) if mine else None
+    # Every rank learns B (and the device) before the first gather, so a rank with no batch at all (fewer batches than
+    # ranks) can contribute zero rows of the right shape instead of leaving the others waiting in the collective.
+    dev = first[0].device if first is not None else (torch.device("cuda", torch.cuda.current_device())
+                                                    if w > 1 and dist.get_backend() == "nccl" else torch.device("cpu"))
+    nb = torch.tensor([first[0].shape[0] if first is not None else 0], dtype=torch.int64, device=dev)
+    if w > 1:
+        dist.all_reduce(nb, op=dist.ReduceOp.MAX)
+    nb = int(nb.item())
     for r in range(rounds):
         if r < len(mine):
-            ids, nids = decode_fn(batches[mine[r]])
-            proto = (ids, nids)
+            ids, nids = first if r == 0 else decode_fn(batches[mine[r]])
         else:
-            if proto is None:
-                raise RuntimeError("decode_sharded: a rank without any batch needs equal-shape batches to pad with")
-            ids, nids = torch.zeros_like(proto[0]), torch.zeros_like(proto[1])
-        assert ids.shape[1] == pad_len
+            ids, nids = torch.zeros((nb, pad_len), dtype=torch.int32, device=dev), torch.zeros((nb,), dtype=torch.int32, device=dev)
+        assert ids.shape == (nb, pad_len), "decode_sharded: batches must have equal B and pad_len columns"
         all_ids, all_n = gather_decoded(ids, nids)
         for src in range(w):
             k = r * w + src

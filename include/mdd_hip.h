@@ -168,6 +168,14 @@ int mdd_fbank(const float *wav_dev, int64_t n_samples, const float *cmvn_scale_d
 int mdd_eval_batch(const int32_t *dec, const int32_t *dec_len, const int32_t *lab, const int32_t *lab_len,
                    const int32_t *can, const int32_t *can_len, int32_t n, int32_t stride, int64_t *counts);
 
+/* ---- Diagnostics (test and measurement aids; no reference counterpart).
+ * mdd_diag_gemm: time one launch form of the split-bf16 projection GEMM on constant operands (abl selects the form;
+ * tools/gemm_*.py).  mdd_diag_gemm_ph8: race screen of the 8-phase GEMM -- the same pseudo-random operands through the
+ * single-barrier kernel once and the 8-phase kernel `reps` times; *mismatches_out = C words that ever differed (must be 0;
+ * tests/test_gpu_parity.py::test_gemm_8phase_race_screen). */
+int mdd_diag_gemm(int M, int N, int K, int abl, int iters, float *ms_out);
+int mdd_diag_gemm_ph8(int M, int N, int K, int reps, unsigned seed, unsigned *mismatches_out);
+
 #ifdef __cplusplus
 }
 #endif

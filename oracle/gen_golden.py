@@ -16,6 +16,7 @@ What is imported:
   AA/infer.py                align_canonical_decoded / stastics / print_aligned_string
                              (function definitions only, extracted with ast because the
                              module has import-time argparse + absent deps) -> G7
+  all of the above chained as AA/infer.py:294-342 does, at T'=250 -> G9 (g9_chain.*)
   torch.nn.CTCLoss(reduction='sum') as called at AA/steps/train_ctc.py:72,186 -> G5
 
 Usage:  python oracle/gen_golden.py            (writes tests/golden/*)
@@ -509,9 +510,102 @@ def gen_input_goldens():
     print("G6 input: %d stack cases, %d length rows" % (len(shapes), len(rows)))
 
 
+# ----------------------------------------------------------------------------- G9 (long goldens + end-to-end chain)
+CHAIN_CASES = (
+    # tag, geometry, B, T (stacked frames), L, seed     -- T=500 is the benchmarked length (T'=250 posterior frames)
+    ("h384_t500", dict(synth.REFERENCE), 3, 500, 40, 2025),
+    ("h256_t500", dict(synth.REFERENCE_256), 2, 500, 40, 2026),
+    ("h384_t64", dict(synth.REFERENCE), 4, 64, 7, 2027),
+)
+
+
+def chain_records(logp, frac, x1, tlen, int2char, beam, greedy, helpers):
+    """The loop of AA/infer.py:294-342 on one batch of posteriors, run with the reference's own decoders, wer,
+    align_canonical_decoded and stastics; returns one record per utterance."""
+    probs = torch.from_numpy(logp)
+    lens = (torch.from_numpy(frac) * probs.size(0)).long().numpy().tolist()          # infer.py:296-297
+    dec_beam = beam.decode(probs, lens)                                              # what infer.py runs (decode_type != 'Greedy')
+    dec_greedy = greedy.decode(probs, lens)
+    recs = []
+    for b in range(len(lens)):
+        canonical = " ".join(int2char[int(n)] for n in x1[b][:tlen[b]])              # infer.py:303-306
+        rec = dict(len=lens[b], canonical=canonical, beam=dec_beam[b], greedy=dec_greedy[b])
+        for name, hyp in (("beam", dec_beam[b]), ("greedy", dec_greedy[b])):
+            hyp_ns = " ".join(p for p in hyp.split(" ") if p != "sil")               # :311-318
+            can_ns = " ".join(p for p in canonical.split(" ") if p != "sil")
+            hyp_ns = hyp_ns.replace("err", "").replace("  ", " ")                    # :322-323
+            try:
+                dist, path = greedy.wer(hyp_ns, can_ns)                              # :324
+            except TypeError:                                                        # an empty side: ctcDecoder.py:137-138
+                rec[name + "_chain"] = dict(error="TypeError")
+                continue
+            pd = [c for c in hyp_ns.split(" ") if c]
+            pc = [c for c in can_ns.split(" ") if c]
+            pd, pc, path2 = helpers["align_canonical_decoded"](pd, pc, list(path))   # :333
+            ds = sum(1 for c in path2 if c in "DS")
+            cor = sum(1 for c in path2 if c == "-")
+            ins, sub, dele = helpers["stastics"](path2, pc, pd)                      # :338
+            tmp = min(len(ins) / 4, 0.1 * (cor + ds))
+            score = math.ceil((1 - (ds + tmp) / (ds + cor)) * 100)                   # :339-340
+            rec[name + "_chain"] = dict(dist=int(dist), ops=list(path), al_hyp=pd, al_can=pc, al_ops=path2, ins=ins, sub=sub,
+                                        dele=dele, correct=cor, del_sub=ds, score=score)
+        recs.append(rec)
+    return recs
+
+
+def gen_chain_goldens():
+    """G2-long: reference log-probs at the benchmarked length (T'=250), ragged lengths and ragged L, H=384 and H=256;
+    G9: the reference's whole chain on them: model -> BeamDecoder(10) / GreedyDecoder -> wer -> align -> stastics -> score.
+    Also the WAV of egs/vocabulary/single through OUR restatement of Kaldi's fbank (Kaldi itself is absent: parity of the
+    features is unpinned) and from there on through the reference's chain."""
+    int2char = synth.phone_table_41()
+    arpa = os.path.join(OUT, "lm_synth45.arpa")
+    helpers = load_infer_functions()
+    greedy = GreedyDecoder(int2char, space_idx=-1, blank_index=0)
+    beam = BeamDecoder(int2char, beam_width=10, blank_index=0, space_idx=-1, lm_path=arpa, lm_alpha=0.0)   # ctc_config.0329.yaml:87-88
+    arrays, meta = {}, []
+    for tag, g, B, T, L, seed in CHAIN_CASES:
+        geom = synth.Geometry(**g)
+        sd = synth.synth_state_dict(geom, seed=seed)
+        x, x1, frac, tlen = synth.synth_batch(geom, B=B, T=T, L=L, seed=seed)
+        m = build_reference_model(geom, sd)
+        with torch.no_grad():
+            logp = m(torch.from_numpy(x), torch.from_numpy(x1)).numpy()
+        arrays[tag + "_logp"] = logp
+        srt = np.sort(logp, axis=-1)
+        recs = chain_records(logp, frac, x1, tlen, int2char, beam, greedy, helpers)
+        meta.append(dict(tag=tag, geom=g, B=B, T=T, L=L, seed=seed, min_top2_gap=float((srt[..., -1] - srt[..., -2]).min()),
+                         records=recs))
+        print("G9", tag, logp.shape, "beam lens", [len(r["beam"].split()) for r in recs], "scores", [r["beam_chain"]["score"] for r in recs])
+    # the WAV fixture: features by oracle.fbank + CMVN + stack/skip (ours), then the reference model and chain
+    sys.path.insert(0, ROOT)
+    from oracle import oracle as orc
+    sys.path.pop(0)
+    import wave
+    w = wave.open(os.path.join(OUT, "vocabulary_single_1.wav"))
+    wav = np.frombuffer(w.readframes(w.getnframes()), dtype=np.int16).astype(np.float32)
+    feats = orc.stack_skip(orc.apply_cmvn(orc.fbank(wav), orc.read_cmvn_stats(os.path.join(OUT, "global_fbank_cmvn.txt"))))
+    geom = synth.Geometry(**synth.REFERENCE)
+    sd = synth.synth_state_dict(geom, seed=11)
+    canon = "v ow k ae b y ah l eh r iy"
+    c2i = {v: k for k, v in int2char.items()}
+    x1 = np.array([[c2i[p] for p in canon.split()]], dtype=np.int64)
+    m = build_reference_model(geom, sd)
+    with torch.no_grad():
+        logp = m(torch.from_numpy(feats[None]), torch.from_numpy(x1)).numpy()
+    arrays["wav_feats"] = feats
+    arrays["wav_logp"] = logp
+    recs = chain_records(logp, np.ones(1, dtype=np.float32), x1, np.array([x1.shape[1]]), int2char, beam, greedy, helpers)
+    meta.append(dict(tag="wav", geom=dict(synth.REFERENCE), B=1, T=int(feats.shape[0]), L=int(x1.shape[1]), seed=11, canonical=canon,
+                     records=recs))
+    print("G9 wav", logp.shape, recs[0]["beam"], recs[0]["beam_chain"]["score"])
+    np.savez_compressed(os.path.join(OUT, "g9_chain.npz"), **arrays)
+    json.dump(meta, open(os.path.join(OUT, "g9_chain.json"), "w"))
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ["model", "decode", "align", "eval", "ctc", "input"]
+    which = sys.argv[1:] or ["model", "decode", "align", "eval", "ctc", "input", "chain"]
     with torch.no_grad():
         if "model" in which:
             gen_model_goldens()
@@ -525,3 +619,5 @@ if __name__ == "__main__":
         gen_ctc_goldens()
     if "input" in which:
         gen_input_goldens()
+    if "chain" in which:
+        gen_chain_goldens()

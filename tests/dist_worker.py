@@ -34,6 +34,8 @@ def main(rank, world_size, port):
         return ids, nids
     res = mdist.decode_sharded(batches, decode_fn, pad_len=6)
     flat = [(int(res[k][0][i, 0]), int(res[k][1][i])) for k in range(5) for i in range(3)]
+    one = mdist.decode_sharded(batches[:1], decode_fn, pad_len=6)        # fewer batches than ranks: rank 1 has nothing to decode
+    assert len(one) == 1 and one[0][0][:, 0].tolist() == [0, 1, 2] and one[0][1].tolist() == [1, 2, 3]
     tot = mdist.sum_counts([rank + 1, 10 * (rank + 1), 0, 0, 0, 0, 0, 7])
     assert tot == [sum(r + 1 for r in range(world_size)), 10 * sum(r + 1 for r in range(world_size)), 0, 0, 0, 0, 0, 7 * world_size]
     dist.barrier()

@@ -195,3 +195,33 @@ def test_fbank_host_side_wire_formats(tmp_path):
     x = np.random.Generator(np.random.PCG64(1)).standard_normal((5, 81)).astype(np.float32)
     np.testing.assert_allclose(x * sc + of, oracle.apply_cmvn(x, stats), rtol=1e-5, atol=1e-5)
 
+
+
+@pytest.mark.parametrize("idx", [0, 1, 2, 3])
+def test_g9_benchmarked_length_and_chain(idx):
+    """G9: reference log-probs at the benchmarked length (T'=250, ragged, H=384 and H=256) and the reference's whole
+    infer.py chain on them (model -> Beam(10)/Greedy -> wer -> align_canonical_decoded -> stastics -> score).  The oracle
+    must land within its budget on the log-probs, and -- fed its OWN log-probs, not the reference's -- produce the same
+    strings, op paths and scores through the host chain of the product (Decoder.wer = mdd_align, infer_core)."""
+    from tests.helpers import chain_inputs, check_chain
+    from ctc_attention_mispronunciation_amd.utils.ctcDecoder import Decoder
+    from ctc_attention_mispronunciation_amd.utils.NgramLM import LanguageModel
+    from ctc_attention_mispronunciation_amd.infer_core import diagnose
+    meta = jload("g9_chain.json")[idx]
+    g = npz("g9_chain.npz")
+    geom, sd, x, x1, frac, tlen = chain_inputs(meta)
+    if x is None:
+        x = g["wav_feats"][None]
+    ref = g[meta["tag"] + "_logp"]
+    logp = oracle.forward(sd, x, x1)
+    np.testing.assert_allclose(logp, ref, rtol=0, atol=TOL_ORACLE)
+    i2c = synth.phone_table_41()
+    lens = [oracle.lib().orc_len_frames(float(f), ref.shape[0]) for f in frac]
+    assert lens == [r["len"] for r in meta["records"]]
+    table = LanguageModel(os.path.join(GOLD, "lm_synth45.arpa")).dense_table(i2c, 45)
+    ids, st = oracle.beam(logp, lens, table, beam_width=10, alpha=0.0)
+    assert not st.any()
+    dec = Decoder(i2c, space_idx=-1, blank_index=0)
+    check_chain(meta["records"], [ids_to_beam_string(s, i2c) for s in ids],
+                [ids_to_greedy_string(s, i2c) for s in oracle.greedy(logp, lens)], dec.wer,
+                lambda hyp, can: diagnose(hyp, can, dec))
