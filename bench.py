@@ -6,7 +6,14 @@ already resident in HBM: stack/skip (A1) -> CTC_Model.forward (A2-A7) -> CTC pre
 (A9) -> decoded ids back on the host -> edit-distance alignment against the canonical phonemes (A10).
 Workload (BASELINE.json configs[2], the configuration the metric is quoted on): B=64 utterances of 10 s
 (1000 x 81 log-mel+energy frames -> 250 posterior frames each), 4xBiLSTM-384, 41-phone set (45 classes),
-canonical length 40, beam 10, lm_alpha 0.  `--workload greedy32` runs configs[1] (B=32, greedy decode).
+canonical length 40, beam 10, lm_alpha 0.  `--workload greedy32` runs configs[1] (B=32, greedy decode),
+`--workload ctc256` the CTC alpha/beta lattice (loss + gradient) of configs[4]'s global batch.
+
+The headline `value` fuses `--fuse` (default 8) same-shape batches into one launch sequence, which the
+reference's no-mask semantics allow only for batches of identical T and Lmax.  What real (ragged) data gets is
+reported in the same JSON line under `variants` (same run, rank 0, N=1): `fuse1` (a lone B=64 batch per pass),
+`ragged` (len ~ U[0.5,1] x 10 s, every batch padded to its own maximum, frames counted unpadded), `f32_mode`
+(exact-fp32 MFMA arithmetic, MDD_PRECISION=f32) and `greedy32_h256` (configs[1]).
 
 N>1 (launched by torch.distributed.run, one rank per GPU): utterance batches shard across ranks (weak
 scaling: every rank decodes its own 64-utterance batch) and the posteriors of all shards are all-gathered
@@ -30,6 +37,8 @@ import torch  # noqa: E402
 PEAK_F32_MATRIX_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_* dense peak
 PEAK_BF16_MATRIX_TFLOPS = 2500.0 # dense bf16 MFMA peak (not the 2:1-sparsity figure)
 PEAK_HBM_GBS = 8000.0
+PMC_FILE = os.path.join(ROOT, "profiles", "round2_pmc_traffic.json")
+T_RAW, D_RAW, L_CANON, BEAM_W, N_CLASS = 1000, 81, 40, 10, 45
 
 
 def parse():
@@ -37,187 +46,272 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=256)
     ap.add_argument("--warmup", type=int, default=32)
-    ap.add_argument("--workload", default="joint64", choices=["joint64", "greedy32"])
+    ap.add_argument("--workload", default="joint64", choices=["joint64", "greedy32", "ctc256"])
     ap.add_argument("--hidden", type=int, default=384)
-    ap.add_argument("--lanes", type=int, default=1, help="(must be 1) independent stream pipelines per GPU: two forwards in flight on one "
-                    "device would put two persistent BiLSTM launches side by side, each waiting for CUs the other holds")
     ap.add_argument("--fuse", type=int, default=8, help="reference-sized batches carried by one launch sequence")
+    ap.add_argument("--ragged", action="store_true", help="headline on the ragged set (per-batch padding, unpadded frames counted)")
+    ap.add_argument("--precision", default=None, choices=[None, "f32", "bf16x3"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-variants", action="store_true", help="skip the fuse1 / ragged / f32_mode / greedy32_h256 lines")
     ap.add_argument("--no-gather", action="store_true", help="skip the posterior all-gather at N>1")
     ap.add_argument("--decoder", default=None, choices=[None, "beam", "greedy", "none"], help="diagnostic override of the decode stage")
     ap.add_argument("--no-roofline", action="store_true", help="skip the stage-replay pass (for clean traces)")
-    args = ap.parse_args()
-    if args.lanes != 1:
-        ap.error("--lanes must be 1: a persistent BiLSTM layer needs every CU of the device; batch more work per pass with --fuse instead")
-    return args
+    return ap.parse_args()
 
 
-def main():
-    args = parse()
-    from ctc_attention_mispronunciation_amd import synth, _lib
-    from ctc_attention_mispronunciation_amd.hip_model import HipModel
-    from ctc_attention_mispronunciation_amd.utils.ctcDecoder import GreedyDecoder, BeamDecoder, align_ids_batch
-    from ctc_attention_mispronunciation_amd.utils.data_loader import stack_features
+class Ctx(object):
+    """Process-wide pieces: rank layout, torch.distributed handle."""
 
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
-    _lib.require_gpu()
-    ndev = torch.cuda.device_count()
-    if local >= ndev:            # rehearsal of the N>1 path on a box with fewer GPUs than ranks (MDD_DIST_BACKEND=gloo)
-        local = local % ndev
-    torch.cuda.set_device(local)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        backend = os.environ.get("MDD_DIST_BACKEND", "nccl")   # "nccl" is RCCL on ROCm
-        if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+    def __init__(self, args):
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local = int(os.environ.get("LOCAL_RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        if self.world != args.gpus and self.world > 1:
+            raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, self.world))
+        ndev = torch.cuda.device_count()
+        if self.local >= ndev:        # rehearsal of the N>1 path on a box with fewer GPUs than ranks (MDD_DIST_BACKEND=gloo)
+            self.local = self.local % ndev
+        torch.cuda.set_device(self.local)
+        self.dist = None
+        if self.world > 1:
+            import torch.distributed as dist
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            backend = os.environ.get("MDD_DIST_BACKEND", "nccl")   # "nccl" is RCCL on ROCm
+            if backend == "nccl":
+                dist.init_process_group("nccl", rank=self.rank, world_size=self.world, device_id=torch.device("cuda", self.local))
+            else:
+                dist.init_process_group(backend, rank=self.rank, world_size=self.world)
+            self.dist = dist
+
+    def barrier(self):
+        torch.cuda.synchronize()
+        if self.dist is not None:
+            self.dist.barrier()
+        torch.cuda.synchronize()
+
+
+class DecodeJob(object):
+    """One configuration of the hot path: model, resident inputs, two-stream pipeline (forward of pass i+1 on s_fwd
+    beside the beam search + D2H of pass i on s_dec; the host aligns pass i meanwhile)."""
+
+    def __init__(self, ctx, args, hidden, joint, fuse, ragged, precision, decoder_kind=None, gather=True):
+        from ctc_attention_mispronunciation_amd import synth, dist as mdist
+        from ctc_attention_mispronunciation_amd.hip_model import HipModel
+        from ctc_attention_mispronunciation_amd.utils.ctcDecoder import GreedyDecoder, BeamDecoder
+        from ctc_attention_mispronunciation_amd.utils.data_loader import stack_features
+        self.ctx, self.joint, self.ragged, self.fuse = ctx, joint, ragged, fuse
+        self.mdist = mdist
+        self.B0 = 64 if joint else 32
+        self.geom = synth.Geometry(feat=3 * D_RAW, hidden=hidden, layers=4, num_class=N_CLASS)
+        self.sd = synth.synth_state_dict(self.geom, seed=1234)
+        self.model = HipModel(self.geom, self.sd, device=ctx.local, precision=precision)
+        self.i2c = synth.phone_table_41()
+        arpa = os.path.join(ROOT, "tests", "golden", "lm_synth45.arpa")
+        kind = decoder_kind or ("beam" if joint else "greedy")
+        self.decoder_kind = kind
+        self.decoder = (BeamDecoder(self.i2c, beam_width=BEAM_W, blank_index=0, space_idx=-1, lm_path=arpa, lm_alpha=0.0)
+                        if kind == "beam" else GreedyDecoder(self.i2c, space_idx=-1, blank_index=0))
+        self.gather = gather and ctx.world > 1
+        self.s_fwd, self.s_dec = torch.cuda.Stream(), torch.cuda.Stream()
+        self.ev_fwd = [torch.cuda.Event() for _ in range(2)]
+        self.ev_dec = [torch.cuda.Event() for _ in range(2)]
+        self.ev_free = [torch.cuda.Event() for _ in range(2)]
+        self.count = 0
+        self.aligned = []
+        self.frames_done = 0
+        seed = 1234 + ctx.rank                                   # every rank decodes a different shard, same shapes
+        if not ragged:
+            # fuse G same-shape batches per pass; a step stays one B0-utterance batch
+            nb = fuse
+            self.raw = torch.from_numpy(synth.synth_raw_features(self.B0 * nb, T_RAW, D_RAW, seed=seed)).cuda()
+            _, x1_np, _, _ = synth.synth_batch(self.geom, B=self.B0 * nb, T=T_RAW // 2, L=L_CANON, seed=seed, ragged=False)
+            self.x1_np = x1_np
+            self.x1 = torch.from_numpy(x1_np).cuda()
+            self.sets = {}
         else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+            # 8 different reference batches: len ~ U[0.5,1] x 10 s, each utterance stacked/skipped on its own (the last
+            # frame replicated at ITS edge, data_loader.py:138-142), each batch zero-padded to its own maximum (:159,173)
+            # and run alone (a fused pass needs identical T and Lmax).  Canonical lengths ~ U[0.5,1] x 40, padded per batch.
+            rs = np.random.Generator(np.random.PCG64(seed))
+            self.rag = []
+            for k in range(8):
+                lens_raw = rs.integers(T_RAW // 2, T_RAW + 1, size=self.B0)
+                raw = synth.synth_raw_features(self.B0, T_RAW, D_RAW, seed=seed + 100 * (k + 1))
+                t_st = [int((n + 1) // 2 + ((n + 1) // 2) % 2) for n in lens_raw]        # mdd_stack_len(n, 2, 2)
+                T = max(t_st)
+                x = torch.zeros((self.B0, T, 3 * D_RAW), device="cuda")
+                for b in range(self.B0):
+                    x[b, :t_st[b]] = stack_features(torch.from_numpy(raw[b, :lens_raw[b]]))
+                llen = rs.integers(L_CANON // 2, L_CANON + 1, size=self.B0)
+                Lm = int(llen.max())
+                x1 = np.zeros((self.B0, Lm), dtype=np.int64)
+                for b in range(self.B0):
+                    x1[b, :llen[b]] = rs.integers(2, 44, size=llen[b])
+                frac = torch.tensor([t / T for t in t_st]).float()                          # data_loader.py:177
+                lens = (frac * (T // 2)).long().to(torch.int32)                             # infer.py:296-297
+                self.rag.append(dict(x=x, x1=torch.from_numpy(x1).cuda(), x1_np=x1, lens=lens.cuda(), T=T, canon_len=llen.astype(np.int32),
+                                     frames=int(lens.sum())))
+        torch.cuda.synchronize()
 
-    joint = args.workload == "joint64"
-    import math
-    G = max(1, min(args.fuse, args.steps))            # batches fused per pass; a step stays one 64-utterance batch.  A step
-    # count that is not a multiple of G ends with one smaller pass (its own buffers and captured graph, warmed up too).
-    B0 = 64 if joint else 32
-    B = B0 * G
-    T_raw, D, L, beam_w = 1000, 81, 40, 10
-    geom = synth.Geometry(feat=243, hidden=args.hidden, layers=4, num_class=45)
-    sd = synth.synth_state_dict(geom, seed=1234)
-    # every rank decodes a different shard (different seed), same shapes
-    raw = torch.from_numpy(synth.synth_raw_features(B, T_raw, D, seed=1234 + rank)).cuda()
-    _, x1_np, _, _ = synth.synth_batch(geom, B=B, T=T_raw // 2, L=L, seed=1234 + rank, ragged=False)
-    x1 = torch.from_numpy(x1_np).cuda()
-    model = HipModel(geom, sd, device=local)
-    i2c = synth.phone_table_41()
-    arpa = os.path.join(ROOT, "tests", "golden", "lm_synth45.arpa")
-    use_beam = joint if args.decoder is None else args.decoder == "beam"
-    decoder = (BeamDecoder(i2c, beam_width=beam_w, blank_index=0, space_idx=-1, lm_path=arpa, lm_alpha=0.0)
-               if use_beam else GreedyDecoder(i2c, space_idx=-1, blank_index=0))
-    Tp = T_raw // 4
-    lens = torch.full((B,), Tp, dtype=torch.int32, device="cuda")
-    canon_mat = np.ascontiguousarray(x1_np, dtype=np.int32)
-    canon_len = np.full((B,), canon_mat.shape[1], dtype=np.int32)
+    class Bufs(object):
+        pass
 
-    # Software pipeline.  `lanes` independent batch pipelines are in flight at once (each with its own library
-    # handle = its own workspace and captured graphs): the BiLSTM recurrence is a chain of ~1000 dependent
-    # ~5 us launches per batch that leaves most CUs idle, so interleaving independent batches on separate
-    # HIP streams hides that latency.  Inside a lane the forward of its next batch (stream s_fwd) overlaps the
-    # latency-bound beam search of its previous one (s_dec); the host aligns finished batches meanwhile.
-    class Lane(object):
-        class Bufs(object):
-            def __init__(self, g):
-                b = g * B0
-                self.b = b
-                self.raw = raw[:b]
-                self.x1 = x1[:b]
-                self.lens = lens[:b]
-                self.logp = [torch.empty((Tp, b, geom.num_class), device="cuda") for _ in range(2)]
-                self.gathered = ([torch.empty((world, Tp, b, geom.num_class), device="cuda") for _ in range(2)]
-                                 if world > 1 else None)
-                self.h_ids = [torch.empty((b, Tp), dtype=torch.int32).pin_memory() for _ in range(2)]
-                self.h_n = [torch.empty((b,), dtype=torch.int32).pin_memory() for _ in range(2)]
+    def _bufs(self, key):
+        if key in self.sets:
+            return self.sets[key]
+        bf = DecodeJob.Bufs()
+        g = key
+        b = g * self.B0
+        Tp = T_RAW // 4
+        bf.b, bf.Tp = b, Tp
+        bf.raw, bf.x1 = self.raw[:b], self.x1[:b]
+        bf.lens = torch.full((b,), Tp, dtype=torch.int32, device="cuda")
+        bf.canon = np.ascontiguousarray(self.x1_np[:b], dtype=np.int32)
+        bf.canon_len = np.full((b,), bf.canon.shape[1], dtype=np.int32)
+        bf.frames = b * Tp
+        self._alloc_out(bf)
+        self.sets[key] = bf
+        return bf
 
-        def __init__(self, mdl):
-            self.model = mdl
-            self.s_fwd, self.s_dec = torch.cuda.Stream(), torch.cuda.Stream()
-            self.bufs = {}
-            self.ev_fwd = [torch.cuda.Event() for _ in range(2)]
-            self.ev_dec = [torch.cuda.Event() for _ in range(2)]
-            self.ev_free = [torch.cuda.Event() for _ in range(2)]
-            self.count = 0
+    def _alloc_out(self, bf):
+        w = self.ctx.world
+        bf.logp = [torch.empty((bf.Tp, bf.b, N_CLASS), device="cuda") for _ in range(2)]
+        bf.gathered = [torch.empty((w, bf.Tp, bf.b, N_CLASS), device="cuda") for _ in range(2)] if self.gather else None
+        bf.h_ids = [torch.empty((bf.b, bf.Tp), dtype=torch.int32).pin_memory() for _ in range(2)]
+        bf.h_n = [torch.empty((bf.b,), dtype=torch.int32).pin_memory() for _ in range(2)]
 
-        def enqueue(self, g):
-            if g not in self.bufs:
-                self.bufs[g] = Lane.Bufs(g)
-            bf = self.bufs[g]
-            k = self.count & 1
-            self.count += 1
-            with torch.cuda.stream(self.s_fwd):
-                self.s_fwd.wait_event(self.ev_free[k])          # slot k's buffers no longer read by the decoder two passes ago
+    def _rag_bufs(self, k):
+        r = self.rag[k]
+        if "bf" not in r:
+            bf = DecodeJob.Bufs()
+            bf.b, bf.Tp = self.B0, r["T"] // 2
+            bf.x, bf.x1, bf.lens = r["x"], r["x1"], r["lens"]
+            bf.canon = np.ascontiguousarray(r["x1_np"], dtype=np.int32)
+            bf.canon_len = r["canon_len"]
+            bf.frames = r["frames"]
+            self._alloc_out(bf)
+            r["bf"] = bf
+        return r["bf"]
+
+    def enqueue(self, item):
+        """item: number of fused batches (uniform set) or the index of a ragged batch."""
+        bf = self._rag_bufs(item) if self.ragged else self._bufs(item)
+        k = self.count & 1
+        self.count += 1
+        with torch.cuda.stream(self.s_fwd):
+            self.s_fwd.wait_event(self.ev_free[k])          # slot k's buffers no longer read by the decoder two passes ago
+            if self.ragged:
+                self.model.forward(bf.x, bf.x1, out=bf.logp[k])
+            else:
                 self.model.forward_raw(bf.raw, bf.x1, out=bf.logp[k])    # stack/skip folded into the front-end's tile load
-                if bf.gathered is not None and not args.no_gather:
-                    dist.all_gather_into_tensor(bf.gathered[k].view(-1, bf.b, geom.num_class), bf.logp[k])
-                self.ev_fwd[k].record(self.s_fwd)
-            with torch.cuda.stream(self.s_dec):
-                self.s_dec.wait_event(self.ev_fwd[k])
-                if args.decoder != "none":
-                    out = decoder.decode_ids(bf.logp[k], bf.lens)
-                    bf.h_ids[k].copy_(out[0], non_blocking=True)
-                    bf.h_n[k].copy_(out[1], non_blocking=True)
-                self.ev_free[k].record(self.s_dec)
-                self.ev_dec[k].record(self.s_dec)
-            return (g, k)
+            if bf.gathered is not None:
+                self.mdist.gather_posteriors(bf.logp[k], out=bf.gathered[k])
+            self.ev_fwd[k].record(self.s_fwd)
+        with torch.cuda.stream(self.s_dec):
+            self.s_dec.wait_event(self.ev_fwd[k])
+            if self.decoder_kind != "none":
+                out = self.decoder.decode_ids(bf.logp[k], bf.lens)
+                bf.h_ids[k].copy_(out[0], non_blocking=True)
+                bf.h_n[k].copy_(out[1], non_blocking=True)
+            self.ev_free[k].record(self.s_dec)
+            self.ev_dec[k].record(self.s_dec)
+        return (bf, k)
 
-        def finish(self, gk):
-            g, k = gk
-            bf = self.bufs[g]
-            self.ev_dec[k].synchronize()
-            tot = 0
-            if args.decoder != "none":
-                dist = align_ids_batch(bf.h_ids[k].numpy(), bf.h_n[k].numpy(), canon_mat[:bf.b], canon_len[:bf.b])[0]   # one native call per pass
-                tot = int(dist[dist >= 0].sum())
-            aligned.append(tot)
+    def finish(self, pend):
+        from ctc_attention_mispronunciation_amd.utils.ctcDecoder import align_ids_batch
+        bf, k = pend
+        self.ev_dec[k].synchronize()
+        tot = 0
+        if self.decoder_kind != "none":
+            d = align_ids_batch(bf.h_ids[k].numpy(), bf.h_n[k].numpy(), bf.canon, bf.canon_len)[0]   # one native call per pass
+            tot = int(d[d >= 0].sum())
+        self.aligned.append(tot)
+        self.frames_done += bf.frames
 
-    aligned = []
-    lanes = [Lane(model)] + [Lane(HipModel(geom, sd, device=local)) for _ in range(args.lanes - 1)]
-
-    def passes(nsteps):
+    def items(self, nsteps):
+        if self.ragged:
+            return [i % len(self.rag) for i in range(nsteps)]
+        G = max(1, min(self.fuse, nsteps))
         return [G] * (nsteps // G) + ([nsteps % G] if nsteps % G else [])
 
-    def run(sizes):
+    def run(self, items):
         pending = []
-        for i, g in enumerate(sizes):
-            ln = lanes[i % len(lanes)]
-            pending.append((ln, ln.enqueue(g)))
-            if len(pending) > len(lanes):                    # keep at most one finished-but-unaligned pass per lane
-                l0, k0 = pending.pop(0)
-                l0.finish(k0)
-        for l0, k0 in pending:
-            l0.finish(k0)
+        for it in items:
+            pending.append(self.enqueue(it))
+            if len(pending) > 1:                                 # keep at most one finished-but-unaligned pass
+                self.finish(pending.pop(0))
+        for p in pending:
+            self.finish(p)
 
-    def barrier():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
+    def check_errors(self):
+        """mdd_sync: asynchronous errors of the handle (a persistent BiLSTM launch that timed out waiting for its team
+        leaves garbage posteriors; the throughput of such a run must not be reported)."""
+        from ctc_attention_mispronunciation_amd import _lib
+        for st in (self.s_fwd, self.s_dec):
+            rc = _lib.lib().mdd_sync(self.model.handle, _lib.C.c_void_p(st.cuda_stream))
+            if rc != 0:
+                raise SystemExit("bench: the library reported an asynchronous error: %s" % _lib.lib().mdd_last_error().decode())
 
-    timed = passes(args.steps)
-    warm = passes(max(args.warmup, 1))
-    for g in set(timed) - set(warm):                          # every pass size of the timed region is captured beforehand
-        warm.append(g)
-    run(warm)
-    barrier()
-    aligned.clear()
-    t0 = time.perf_counter()
-    run(timed)
-    barrier()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    frames = world * B0 * Tp * args.steps
-    value = frames / dt
+    def timed(self, steps, warmup):
+        """W untimed warm-up steps (every pass shape of the timed region captured beforehand), then exactly `steps` steps
+        between barrier + synchronize on both sides; MAX over ranks.  Returns (seconds, frames decoded by this rank)."""
+        timed = self.items(steps)
+        warm = self.items(max(warmup, 1))
+        for g in sorted(set(timed) - set(warm)):
+            warm.append(g)
+        self.run(warm)
+        self.ctx.barrier()
+        self.aligned.clear()
+        self.frames_done = 0
+        t0 = time.perf_counter()
+        self.run(timed)
+        self.ctx.barrier()
+        dt = time.perf_counter() - t0
+        self.check_errors()
+        if self.ctx.dist is not None:
+            t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+            if self.ctx.dist.get_backend() == "gloo":
+                t = t.cpu()
+            self.ctx.dist.all_reduce(t, op=self.ctx.dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt, self.frames_done
 
-    # ---- roofline of the dominant kernel, measured with HIP events on the launch stream (stage replay)
-    roof = None
-    stages = None
-    if rank == 0 and not args.no_roofline:
-        x = stack_features(raw)
+    def verify_gather(self):
+        """N>1: every rank's slice of the last gathered buffer equals its own posteriors, and the slices of the other ranks
+        differ from it (they decode different shards).  Returns True/False agreed over all ranks (None at N=1)."""
+        if not self.gather:
+            return None
+        ok = True
+        for bf in ([r["bf"] for r in self.rag if "bf" in r] if self.ragged else list(self.sets.values())):
+            for k in range(2):
+                own = bf.gathered[k][self.ctx.rank]
+                ok = ok and bool(torch.equal(own, bf.logp[k]))
+                ok = ok and all(not torch.equal(bf.gathered[k][r], own) for r in range(self.ctx.world) if r != self.ctx.rank)
+        t = torch.tensor([1.0 if ok else 0.0], device="cpu" if self.ctx.dist.get_backend() == "gloo" else "cuda")
+        self.ctx.dist.all_reduce(t, op=self.ctx.dist.ReduceOp.MIN)
+        return bool(t.item() > 0.5)
+
+    def roofline(self, G):
+        """Roofline of the dominant kernel class, measured with HIP events on the launch stream (stage replay of one
+        uniform pass of G batches)."""
+        from ctc_attention_mispronunciation_amd.utils.data_loader import stack_features
+        model = self.model
+        B = G * self.B0
+        Tp, L = T_RAW // 4, L_CANON
+        if self.ragged:
+            x, x1 = self.rag[0]["x"], self.rag[0]["x1"]
+            Tp, L = x.shape[1] // 2, x1.shape[1]
+        else:
+            x, x1 = stack_features(self.raw[:B]), self.x1[:B]
         torch.cuda.synchronize()
         reps = [model.profile(x, x1) for _ in range(3)]
         stages = [(reps[0][i][0], float(np.median([r[i][1] for r in reps])), reps[0][i][2], reps[0][i][3]) for i in range(len(reps[0]))]
-        # kernel classes: which hand-written kernel a stage runs (depends on the precision mode in use)
         x3 = model.precision == "bf16x3"
-        def kernel_of(name):
+
+        def kernel_of(name):   # which hand-written kernel a stage runs (depends on the precision mode in use)
             if name.startswith("lstm"):
-                return "lstm_layer_granule_kernel" if (x3 and B <= 512) else ("lstm_layer_persistent_kernel" if x3 else "lstm_step_packed_kernel")
+                return "lstm_layer_granule_kernel" if x3 else "lstm_step_packed_kernel"
             if name.startswith("gemm"):
                 if not x3:
                     return "gemm_nt_f32_kernel"
@@ -231,14 +325,13 @@ def main():
         cand = {k: v for k, v in groups.items() if k.startswith(("lstm_", "gemm_"))}
         kern = max(cand, key=lambda k: cand[k][0])
         ms, launches, flops = cand[kern]
-        bf16_kernel = kern in ("gemm_bf16x3_ph8_kernel", "gemm_bf16x3_glds256_kernel", "gemm_bf16x3_glds_kernel", "lstm_layer_granule_kernel", "lstm_layer_persistent_kernel")
+        bf16_kernel = kern in ("gemm_bf16x3_ph8_kernel", "gemm_bf16x3_glds_kernel", "lstm_layer_granule_kernel")
         peak = PEAK_BF16_MATRIX_TFLOPS if bf16_kernel else PEAK_F32_MATRIX_TFLOPS
         achieved = flops / (ms * 1e-3) / 1e12
         traffic = None
-        pmc_file = os.path.join(ROOT, "profiles", "round1_pmc_traffic.json")
-        if os.path.exists(pmc_file):      # HBM bytes per launch from a separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE run of this command
-            traffic = json.load(open(pmc_file)).get(kern)
-        roof = {"kernel": kern, "bound": "mfma", "achieved": round(achieved, 3), "peak": peak,
+        if os.path.exists(PMC_FILE):      # HBM bytes per launch from a separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE run of this command
+            traffic = json.load(open(PMC_FILE)).get(kern)
+        return {"kernel": kern, "bound": "mfma", "achieved": round(achieved, 3), "peak": peak,
                 "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic,
                 "note": ("algorithmic fp32-equivalent flops; the split-bf16 kernels issue 3 bf16 MFMA flops per algorithmic flop "
                          "(frac x3 = matrix-core utilisation)" if bf16_kernel else "fp32 MFMA"),
@@ -249,49 +342,172 @@ def main():
                 "kernel_classes_ms": {k: round(v[0], 4) for k, v in groups.items()},
                 "stage_ms": {n: round(m, 4) for n, m, _, _ in stages}}
 
+    def close(self):
+        self.model.close()
+        self.sets = {}
+        self.rag = []
+        torch.cuda.empty_cache()
+
+
+DTYPE_X3 = ("f32 results from split-bf16 arithmetic: every contraction of the model -- conv0/conv1, the BiLSTM input projections AND the "
+            "recurrent W_hh.h products, text projection, score and attention-score GEMMs -- runs as bf16 hi/lo x3 on the bf16 MFMA pipes "
+            "with fp32 accumulate (operands ~16 significant bits, the recurrent state h is re-split to hi+lo every step); cell state, gates, "
+            "softmax and the classifier tail are fp32.  Log-probs within 1e-4 of the fp32 reference at T'=250 (tests/golden/g9_chain); "
+            "exact-fp32 MFMA mode reported under variants.f32_mode")
+
+
+def variant(ctx, args, name, **kw):
+    """One secondary configuration measured in the same run (rank 0, N=1)."""
+    steps, warmup = kw.pop("steps"), kw.pop("warmup")
+    want_roof = kw.pop("roofline", False)
+    job = DecodeJob(ctx, args, **kw)
+    dt, frames = job.timed(steps, warmup)
+    out = {"value": round(frames / dt, 1), "unit": "phoneme-frames/s", "ms_per_step": round(dt / steps * 1e3, 4), "steps": steps,
+           "batch": job.B0, "batches_fused_per_pass": 1 if job.ragged else max(1, min(job.fuse, steps)), "hidden": kw["hidden"],
+           "decoder": job.decoder_kind, "precision": job.model.precision}
+    if job.ragged:
+        out["padded_frames_per_s"] = round(sum(r["T"] // 2 * job.B0 for r in job.rag) / len(job.rag) * steps / dt, 1)
+    if want_roof and not args.no_roofline:
+        r = job.roofline(max(1, min(job.fuse, steps)))
+        out["roofline"] = {k: r[k] for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "avg_launch_us", "kernel_classes_ms")}
+    job.close()
+    return out
+
+
+def ctc_workload(ctx, args):
+    """configs[4]'s CTC lattice: nn.CTCLoss(reduction='sum') forward + the gradient autograd deposits on the log-probs, global
+    batch 256 x T'=250 x L=40 (one step = one loss+grad over the batch).  HBM-bound scan: the kernel must read logp once for
+    alpha/beta and write the gradient once: 2 x T' x B x C x 4 bytes algorithmic."""
+    from ctc_attention_mispronunciation_amd.hip_model import ctc_loss
+    rs = np.random.Generator(np.random.PCG64(12 + ctx.rank))
+    T, B, Cn, L = T_RAW // 4, 256, N_CLASS, L_CANON
+    lp = torch.log_softmax(torch.from_numpy(rs.standard_normal((T, B, Cn)).astype(np.float32)), -1).cuda()
+    tg = torch.from_numpy(rs.integers(1, Cn, size=(B, L))).cuda()
+    il = torch.from_numpy(rs.integers(2 * L + 1, T + 1, size=B)).cuda()
+    tl = torch.from_numpy(rs.integers(L // 2, L + 1, size=B)).cuda()
+    for _ in range(max(args.warmup, 1)):
+        ctc_loss(lp, tg, il, tl)
+    ctx.barrier()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    for _ in range(args.steps):
+        nll, grad = ctc_loss(lp, tg, il, tl)
+    e1.record()
+    ctx.barrier()
+    dt = time.perf_counter() - t0
+    kern_ms = e0.elapsed_time(e1) / args.steps
+    alg_bytes = 2.0 * T * B * Cn * 4
+    return dt, B * T * args.steps, {"kernel": "ctc_kernel", "bound": "hbm", "achieved": round(alg_bytes / (kern_ms * 1e-3) / 1e9, 2),
+                                    "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(alg_bytes / (kern_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
+                                    "traffic": None, "avg_launch_us": round(kern_ms * 1e3, 2), "bytes_per_launch": alg_bytes,
+                                    "note": "lattice recurrences are T' dependent steps per utterance: latency-, not bandwidth-bound at B=256"}
+
+
+def main():
+    args = parse()
+    from ctc_attention_mispronunciation_amd import _lib
+    _lib.require_gpu()
+    ctx = Ctx(args)
+    rank, world = ctx.rank, ctx.world
+
+    if args.workload == "ctc256":
+        dt, frames, roof = ctc_workload(ctx, args)
+        if rank == 0:
+            print(json.dumps({"metric": "phoneme-frames/sec CTC loss+grad lattice", "value": round(world * frames / dt, 1), "unit": "phoneme-frames/s",
+                              "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
+                              "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32 log-probs, f64 lattice",
+                              "data": "synthetic", "config": {"workload": "CTC alpha/beta lattice loss+grad, B=256 x T'=250 x L=40, C=45"},
+                              "roofline": roof, "cpu_baseline": None}))
+        return
+
+    joint = args.workload == "joint64"
+    job = DecodeJob(ctx, args, hidden=args.hidden, joint=joint, fuse=args.fuse, ragged=args.ragged, precision=args.precision,
+                    decoder_kind=args.decoder, gather=not args.no_gather)
+    dt, frames = job.timed(args.steps, args.warmup)
+    G = 1 if args.ragged else max(1, min(args.fuse, args.steps))
+    if ctx.dist is not None:
+        ft = torch.tensor([frames], dtype=torch.float64, device="cpu" if ctx.dist.get_backend() == "gloo" else "cuda")
+        ctx.dist.all_reduce(ft)
+        frames_all = float(ft.item())
+    else:
+        frames_all = float(frames)
+    value = frames_all / dt
+    precision = job.model.precision
+    checksum = int(sum(job.aligned))
+    gather_ok = job.verify_gather()
+
+    roof = job.roofline(G) if (rank == 0 and not args.no_roofline) else None
+
     # ---- CPU baseline: the torch-CPU + Python-beam port of the reference path on a bounded sample
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.ragged:
         from oracle import ref_port
+        from ctc_attention_mispronunciation_amd.utils.data_loader import stack_features
         ncores = min(os.cpu_count() or 1, 16)
         torch.set_num_threads(ncores)
-        sb = min(B0, 64)                                              # one reference-sized batch: ~10 s of CPU work
-        xs = stack_features(raw[:sb]).cpu().numpy()
-        ref_port.forward(sd, xs[:1, :64], x1_np[:1])                       # warm-up
+        sb, Tp = job.B0, T_RAW // 4                                    # one reference-sized batch: ~10 s of CPU work
+        xs = stack_features(job.raw[:sb]).cpu().numpy()
+        ref_port.forward(job.sd, xs[:1, :64], job.x1_np[:1])          # warm-up
         t1 = time.perf_counter()
-        lp_cpu = ref_port.forward(sd, xs, x1_np[:sb])
+        lp_cpu = ref_port.forward(job.sd, xs, job.x1_np[:sb])
         t_fwd = time.perf_counter() - t1
         t1 = time.perf_counter()
-        if joint:
-            ref_port.beam(lp_cpu, [Tp] * sb, i2c, decoder.lm, beam_w, 0.0)
+        if job.decoder_kind == "beam":
+            ref_port.beam(lp_cpu, [Tp] * sb, job.i2c, job.decoder.lm, BEAM_W, 0.0)
         else:
-            ref_port.greedy(lp_cpu, [Tp] * sb, i2c)
+            ref_port.greedy(lp_cpu, [Tp] * sb, job.i2c)
         t_dec = time.perf_counter() - t1
         cpu = {"value": round(sb * Tp / (t_fwd + t_dec), 1), "unit": "phoneme-frames/s", "cores": ncores, "kind": "port",
                "sample": "%d of the same synthetic 10 s utterances (one batch): torch-CPU forward %.2f s + %s %.2f s"
-                         % (sb, t_fwd, "pure-Python beam(10)" if joint else "greedy", t_dec)}
+                         % (sb, t_fwd, "pure-Python beam(10)" if job.decoder_kind == "beam" else "greedy", t_dec)}
+    decoder_kind = job.decoder_kind
+    job.close()
+
+    # ---- the same hot path in the configurations real data and the other BASELINE configs get (rank 0, N=1 only)
+    variants = None
+    if rank == 0 and world == 1 and not args.no_variants and joint and not args.ragged:
+        variants = {
+            "fuse1": variant(ctx, args, "fuse1", hidden=args.hidden, joint=True, fuse=1, ragged=False, precision=args.precision, steps=32, warmup=8),
+            "ragged": variant(ctx, args, "ragged", hidden=args.hidden, joint=True, fuse=1, ragged=True, precision=args.precision, steps=32, warmup=8),
+            "f32_mode": variant(ctx, args, "f32_mode", hidden=args.hidden, joint=True, fuse=args.fuse, ragged=False, precision="f32", steps=16, warmup=8,
+                                roofline=True),
+            "greedy32_h256": variant(ctx, args, "greedy32_h256", hidden=256, joint=False, fuse=args.fuse, ragged=False, precision=args.precision,
+                                     steps=64, warmup=16),
+            "greedy32_h256_fuse1": variant(ctx, args, "greedy32_h256_fuse1", hidden=256, joint=False, fuse=1, ragged=False, precision=args.precision,
+                                           steps=32, warmup=8),
+        }
 
     if rank == 0:
+        B0 = 64 if joint else 32
         line = {
             "metric": "phoneme-frames/sec joint CTC-attn decode, 41-phone vocab",
             "value": round(value, 1), "unit": "phoneme-frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32 (time-batched contractions as split-bf16 x3 on bf16 MFMA with fp32 accumulate; log-probs within 1e-5 of fp32)" if model.precision == "bf16x3" else "f32",
+            "dtype": DTYPE_X3 if precision == "bf16x3" else "f32 (exact fp32 MFMA everywhere)",
             "data": "synthetic",
             "config": {"workload": ("joint CTC-attn decode: stack/skip + forward + beam(10) + align, B=64 x 10 s x 81-dim log-mel"
                                     if joint else "CTC-only greedy decode: stack/skip + forward + greedy + align, B=32 x 10 s"),
-                       "batch_per_gpu": B0, "global_batch": B0 * world, "batches_fused_per_pass": G, "t_raw": T_raw, "posterior_frames": Tp,
-                       "hidden": args.hidden, "layers": 4, "num_class": 45, "canonical_len": L,
-                       "beam": beam_w if joint else 0, "lm_alpha": 0.0, "batches_in_flight": args.lanes,
+                       "batch_per_gpu": B0, "global_batch": B0 * world, "batches_fused_per_pass": G,
+                       "lengths": "ragged: len ~ U[0.5,1] x 10 s, per-batch padding, unpadded frames counted" if args.ragged else
+                                  "all utterances full length (fusing batches requires identical T and Lmax: see variants.fuse1 / variants.ragged)",
+                       "t_raw": T_RAW, "posterior_frames": T_RAW // 4,
+                       "hidden": args.hidden, "layers": 4, "num_class": N_CLASS, "canonical_len": L_CANON,
+                       "decoder": decoder_kind, "beam": BEAM_W if decoder_kind == "beam" else 0, "lm_alpha": 0.0,
                        "parallelism": "utterance-batch shards x%d%s" % (world, ", all-gather posteriors" if world > 1 and not args.no_gather else ""),
                        "posteriors": "random-weight model output (flat: every frame live, beam worst case)"},
-            "roofline": roof, "cpu_baseline": cpu,
-            "edit_distance_checksum": int(sum(aligned)),
+            "roofline": roof, "cpu_baseline": cpu, "variants": variants,
+            "edit_distance_checksum": checksum,
         }
+        if gather_ok is not None:
+            line["gather_verified"] = gather_ok
+        if variants:
+            for k in ("fuse1", "ragged", "f32_mode", "greedy32_h256"):
+                line[k] = variants[k]["value"]
         print(json.dumps(line))
-    if dist is not None:
-        dist.destroy_process_group()
+    if ctx.dist is not None:
+        ctx.dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -127,15 +127,23 @@ static SplitPtr split_view(const DevBuf &b, size_t n) {
 }
 static const SplitPtr kNoSplit = {nullptr, nullptr};
 
-static bool g_ws_moved = false;  // a workspace buffer was reallocated: captured graphs hold stale pointers
+// a workspace buffer was reallocated: captured graphs of THIS thread's handle hold stale pointers (set by ensure(), consumed
+// by the forward_prepare() call that ran it; thread-local because handles on different host threads prepare concurrently)
+static thread_local bool g_ws_moved = false;
 
-static int ensure(DevBuf &b, size_t n) {
+// Workspace growth (hipFree / hipMalloc / clearing) and stream capture exclude each other process-wide: a capture in
+// progress on one host thread makes another thread's allocation-time calls fail ("operation would make the legacy
+// stream depend on a capturing stream").  Both are rare (first call of a shape); graph REPLAYS never take this lock.
+static std::mutex g_prep_mu;
+
+static int ensure(DevBuf &b, size_t n, hipStream_t zero_stream) {
     if (b.cap >= n) return MDD_OK;
     g_ws_moved = true;
     if (b.p) MDD_HIP_CHECK(hipFree(b.p));
     b.p = nullptr; b.cap = 0;
     MDD_HIP_CHECK(hipMalloc((void **)&b.p, n * sizeof(float)));
-    MDD_HIP_CHECK(hipMemset(b.p, 0, n * sizeof(float)));  // padded batch rows of the packed h exchange must be finite
+    MDD_HIP_CHECK(hipMemsetAsync(b.p, 0, n * sizeof(float), zero_stream));  // padded batch rows of the packed h exchange must be finite
+    MDD_HIP_CHECK(hipStreamSynchronize(zero_stream));
     b.cap = n;
     return MDD_OK;
 }
@@ -543,28 +551,30 @@ static int forward_prepare(mdd_model *m, const float *x_dev, int32_t B, int32_t 
     if (B <= 0 || T < 2 || L <= 0) { set_error("mdd_forward: bad shape B=%d T=%d L=%d", B, T, L); return MDD_ERR_ARG; }
     if (T % 2) { set_error("mdd_forward: T must be even (data_loader.py:140-142 pads to n_downsample)"); return MDD_ERR_ARG; }
     MDD_HIP_CHECK(hipSetDevice(m->device));
+    std::lock_guard<std::mutex> prep_lock(g_prep_mu);
+    hipStream_t zs = m->cap_stream;
     const mdd_config &c = m->cfg;
     const int H = c.hidden, Tp = T / 2;
     int rc;
     const size_t rows = (size_t)Tp * B, trows = (size_t)L * B, mrows = rows > trows ? rows : trows;
-    if ((!m->conv_fused() && (rc = ensure(m->y0, (size_t)B * c.channels * T * m->W1()))) || (rc = ensure(m->seq0, rows * m->rnn_in())) ||
-        (rc = ensure(m->gx, mrows * 8 * H)) || (rc = ensure(m->act[0], rows * 2 * H)) || (rc = ensure(m->act[1], rows * 2 * H)) ||
-        (rc = ensure(m->xraw, rows * 2 * H)) || (rc = ensure(m->hbuf, (size_t)4 * ((B + 15) / 16 * 16) * H)) || (rc = ensure(m->cbuf, (size_t)2 * ((B + 15) / 16 * 16) * H)) ||
-        (rc = ensure(m->embo, trows * c.emb_dim)) || (rc = ensure(m->text, trows * 2 * H)) || (rc = ensure(m->key, trows * 2 * H)) ||
-        (rc = ensure(m->S, (size_t)B * Tp * L)))
+    if ((!m->conv_fused() && (rc = ensure(m->y0, (size_t)B * c.channels * T * m->W1(), zs))) || (rc = ensure(m->seq0, rows * m->rnn_in(), zs)) ||
+        (rc = ensure(m->gx, mrows * 8 * H, zs)) || (rc = ensure(m->act[0], rows * 2 * H, zs)) || (rc = ensure(m->act[1], rows * 2 * H, zs)) ||
+        (rc = ensure(m->xraw, rows * 2 * H, zs)) || (rc = ensure(m->hbuf, (size_t)4 * ((B + 15) / 16 * 16) * H, zs)) || (rc = ensure(m->cbuf, (size_t)2 * ((B + 15) / 16 * 16) * H, zs)) ||
+        (rc = ensure(m->embo, trows * c.emb_dim, zs)) || (rc = ensure(m->text, trows * 2 * H, zs)) || (rc = ensure(m->key, trows * 2 * H, zs)) ||
+        (rc = ensure(m->S, (size_t)B * Tp * L, zs)))
         return rc;
-    if (m->x3() && ((rc = ensure(m->seq0_s, rows * m->rnn_in())) || (rc = ensure(m->act_s[0], rows * 2 * H)) ||
-                    (rc = ensure(m->act_s[1], rows * 2 * H)) || (rc = ensure(m->x_s, rows * 2 * H)) ||
-                    (rc = ensure(m->embo_s, trows * c.emb_dim)) || (rc = ensure(m->text_s, trows * 2 * H)) ||
-                    (rc = ensure(m->key_s, trows * 2 * H)) || (rc = ensure(m->hsplit, (size_t)4 * B * H)) ||
-                    (rc = ensure(m->hx, (size_t)2 * 32 * granule_bg(B) * H * 2 + 64 + 256 * 6 * 2))))   // u64 granules (covers the counter form too) + stamps
+    if (m->x3() && ((rc = ensure(m->seq0_s, rows * m->rnn_in(), zs)) || (rc = ensure(m->act_s[0], rows * 2 * H, zs)) ||
+                    (rc = ensure(m->act_s[1], rows * 2 * H, zs)) || (rc = ensure(m->x_s, rows * 2 * H, zs)) ||
+                    (rc = ensure(m->embo_s, trows * c.emb_dim, zs)) || (rc = ensure(m->text_s, trows * 2 * H, zs)) ||
+                    (rc = ensure(m->key_s, trows * 2 * H, zs)) || (rc = ensure(m->hsplit, (size_t)4 * B * H, zs)) ||
+                    (rc = ensure(m->hx, (size_t)2 * 32 * granule_bg(B) * H * 2 + 64 + 256 * 6 * 2, zs))))   // u64 granules (covers the counter form too) + stamps
         return rc;
     if (m->taps) {
         m->tap_rnn.resize(c.layers);
-        for (int n = 0; n + 1 < c.layers; n++) if ((rc = ensure(m->tap_rnn[n], rows * 2 * H))) return rc;
+        for (int n = 0; n + 1 < c.layers; n++) if ((rc = ensure(m->tap_rnn[n], rows * 2 * H, zs))) return rc;
     }
     m->lastB = B; m->lastT = T; m->lastL = L;
-    if (g_ws_moved) {
+    if (g_ws_moved) {   // hipFree above synchronised the device, so no replay of an old graph is still running
         for (auto &kv : m->graphs) (void)hipGraphExecDestroy(kv.second);
         m->graphs.clear();
         g_ws_moved = false;
@@ -591,6 +601,7 @@ extern "C" int mdd_forward(mdd_model *m, const float *x_dev, int32_t B, int32_t 
     if (it == m->graphs.end()) {
         if (m->graphs.size() >= 8) { for (auto &kv : m->graphs) (void)hipGraphExecDestroy(kv.second); m->graphs.clear(); }
         hipGraph_t graph = nullptr;
+        std::lock_guard<std::mutex> prep_lock(g_prep_mu);
         MDD_HIP_CHECK(hipStreamBeginCapture(m->cap_stream, hipStreamCaptureModeRelaxed));
         rc = forward_enqueue(m, x_dev, B, T, x1_dev, L, logp_dev, m->cap_stream);
         hipError_t e = hipStreamEndCapture(m->cap_stream, &graph);
@@ -622,7 +633,11 @@ extern "C" int mdd_forward_raw(mdd_model *m, const float *raw_dev, int32_t B, in
         return rc;
     }
     MDD_HIP_CHECK(hipSetDevice(m->device));
-    if (int rc = ensure(m->xstack, (size_t)B * T * m->cfg.feat)) return rc;
+    {
+        std::lock_guard<std::mutex> prep_lock(g_prep_mu);
+        if (int rc = ensure(m->xstack, (size_t)B * T * m->cfg.feat, m->cap_stream)) return rc;
+    }
+    if (g_ws_moved) { for (auto &kv : m->graphs) (void)hipGraphExecDestroy(kv.second); m->graphs.clear(); g_ws_moved = false; }
     if (int rc = mdd_stack_skip(raw_dev, B, T_raw, D, 2, 2, 2, m->xstack.p, stream)) return rc;
     return mdd_forward(m, m->xstack.p, B, T, x1_dev, L, logp_dev, stream);
 }
@@ -649,9 +664,11 @@ extern "C" int mdd_forward_profile(mdd_model *m, const float *x_dev, int32_t B, 
     for (int si = 0; si < ns; si++) {
         Stage info;
         hipGraph_t graph = nullptr;
+        std::unique_lock<std::mutex> prep_lock(g_prep_mu);
         MDD_HIP_CHECK(hipStreamBeginCapture(m->cap_stream, hipStreamCaptureModeRelaxed));
         rc = run_stage(m, si, x_dev, B, T, x1_dev, L, logp_dev, m->cap_stream, &info);
         hipError_t e = hipStreamEndCapture(m->cap_stream, &graph);
+        prep_lock.unlock();
         if (rc || e != hipSuccess) { if (graph) (void)hipGraphDestroy(graph); if (!rc) set_error("stage capture failed"); return rc ? rc : MDD_ERR_HIP; }
         if (info.launches == 0) {   // stage folded into a neighbour in this configuration
             (void)hipGraphDestroy(graph);

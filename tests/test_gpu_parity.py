@@ -522,3 +522,68 @@ def test_gemm_8phase_race_screen(M, N, K):
         assert rc == 0, L.mdd_last_error().decode()
         assert bad.value == 0, (M, N, K, seed, bad.value)
 
+
+
+def test_two_handles_two_streams_share_one_device():
+    """Two HipModels, two host threads, two HIP streams, one device, B=64 at full length: a persistent BiLSTM layer needs
+    every CU, so the library orders such forwards behind one another per device (api.hip DeviceGate) instead of letting
+    their workgroups starve each other until the wall-clock abort.  Both must return the single-handle bits, with no
+    MDD_ERR_HIP from mdd_sync."""
+    import threading
+    geom = synth.Geometry(**synth.REFERENCE)
+    sd = synth.synth_state_dict(geom, seed=1234)
+    batches = []
+    for k in range(2):
+        x, x1, _, _ = synth.synth_batch(geom, B=64, T=500, L=40, seed=50 + k, ragged=True)
+        batches.append((_cuda(x), _cuda(x1)))
+    solo = _hip().HipModel(geom, sd, precision="bf16x3")
+    want = [solo.forward(x, x1, sync_errors=True).cpu().numpy() for x, x1 in batches]
+    models = [_hip().HipModel(geom, sd, precision="bf16x3") for _ in range(2)]
+    streams = [torch.cuda.Stream() for _ in range(2)]
+    got, errs = [[], []], []
+    start = threading.Barrier(2)
+
+    def worker(k):
+        try:
+            torch.cuda.set_device(0)
+            x, x1 = batches[k]
+            with torch.cuda.stream(streams[k]):
+                start.wait()
+                for _ in range(6):                       # several forwards in flight per stream, interleaved with the other's
+                    got[k].append(models[k].forward(x, x1, out=None))
+                models[k].forward(x, x1, sync_errors=True)
+        except Exception as e:  # noqa: BLE001
+            errs.append(repr(e))
+    torch.cuda.synchronize()
+    th = [threading.Thread(target=worker, args=(k,)) for k in range(2)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    torch.cuda.synchronize()
+    assert not errs, errs
+    for k in range(2):
+        for lp in got[k]:
+            np.testing.assert_array_equal(lp.cpu().numpy(), want[k])
+
+
+def test_bench_two_ranks_rehearsal():
+    """The N>1 path of bench.py, rehearsed as 2 ranks on the ONE GPU of this box: launched exactly as the driver launches
+    it (torch.distributed.run), gloo instead of RCCL (two ranks cannot form an RCCL ring on one device) and the per-step
+    BiLSTM kernels (a persistent layer needs every CU of the device; the per-device gate is per process).  Checks the
+    contract line, n_gpus, and that each rank's slice of the gathered posteriors is its own output."""
+    import socket
+    import subprocess
+    import sys
+    from tests.helpers import ROOT
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, MDD_DIST_BACKEND="gloo", MDD_LSTM="step", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--fuse", "1",
+           "--no-cpu-baseline", "--no-roofline"]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 2 and out["scaling"] == "weak" and out["value"] > 0
+    assert out["config"]["global_batch"] == 128 and "all-gather" in out["config"]["parallelism"]
+    assert out["gather_verified"] is True
