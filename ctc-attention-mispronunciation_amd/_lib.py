@@ -15,7 +15,7 @@ MDD_ERR_EMPTY = -5   # include/mdd_hip.h: an empty sequence where the reference 
 EXPORTS = (
     "mdd_last_error", "mdd_version", "mdd_create", "mdd_destroy", "mdd_load_weight", "mdd_finalize_weights",
     "mdd_set_precision", "mdd_get_precision", "mdd_stack_len", "mdd_stack_skip", "mdd_len_frames", "mdd_forward", "mdd_forward_raw", "mdd_forward_num_stages", "mdd_forward_profile", "mdd_tap", "mdd_tap_copy", "mdd_enable_taps", "mdd_sync",
-    "mdd_greedy", "mdd_beam", "mdd_ctc_loss", "mdd_align", "mdd_align_batch", "mdd_eval_batch", "mdd_fbank_num_frames", "mdd_fbank",
+    "mdd_greedy", "mdd_beam", "mdd_ctc_loss", "mdd_ctc_workspace_bytes", "mdd_align", "mdd_align_batch", "mdd_eval_batch", "mdd_fbank_num_frames", "mdd_fbank",
     "mdd_diag_gemm", "mdd_diag_gemm_ph8",
 )
 
@@ -69,7 +69,9 @@ def lib():
     L.mdd_sync.argtypes = [vp, vp]
     L.mdd_greedy.argtypes = [vp, i32, i32, i32, vp, i32, vp, vp, vp]
     L.mdd_beam.argtypes = [vp, i32, i32, i32, vp, i32, i32, vp, C.c_double, vp, vp, vp, vp, vp]
-    L.mdd_ctc_loss.argtypes = [vp, i32, i32, i32, vp, i32, vp, vp, i32, vp, vp, vp]
+    L.mdd_ctc_loss.argtypes = [vp, i32, i32, i32, vp, i32, vp, vp, i32, vp, vp, vp, C.c_int64, vp]
+    L.mdd_ctc_workspace_bytes.argtypes = [i32, i32, i32, i32, i32]
+    L.mdd_ctc_workspace_bytes.restype = C.c_int64
     L.mdd_align.argtypes = [vp, i32, vp, i32, C.POINTER(i32), vp, C.POINTER(i32)]
     L.mdd_align_batch.argtypes = [vp, vp, i32, vp, vp, i32, i32, vp, vp, i32, vp]
     L.mdd_eval_batch.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, vp]

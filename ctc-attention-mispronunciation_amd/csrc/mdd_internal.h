@@ -80,6 +80,7 @@ int launch_attn_tail(const float *S, int Lp, const float *X, const float *V, con
                      const float *wfc, const float *wfcp, float *logp, int Tp, int B, int L, int H2, int C, hipStream_t st);
 
 int init_kernel_attributes();
+int init_ctc_attributes();
 int init_lstm_attributes();
 int init_persistent_attributes();
 // One launch for the whole layer (256 co-resident workgroups, team-synchronised; see lstm.hip).  hx: exchange buffer

@@ -116,8 +116,11 @@ def ctc_loss(logp, targets, in_len, tgt_len, blank=0, want_grad=True):
     tl = tgt_len.to(dev, torch.int64).contiguous()
     nll = torch.empty((B,), dtype=torch.float32, device=dev)
     grad = torch.empty_like(logp) if want_grad else None
-    _lib.check(_lib.lib().mdd_ctc_loss(C.c_void_p(logp.data_ptr()), T, B, Cn, C.c_void_p(tg.data_ptr()), tg.shape[1],
-                                       C.c_void_p(il.data_ptr()), C.c_void_p(tl.data_ptr()), blank,
-                                       C.c_void_p(nll.data_ptr()), C.c_void_p(grad.data_ptr()) if want_grad else None,
-                                       _lib.current_stream_ptr()))
+    nws = _lib.lib().mdd_ctc_workspace_bytes(T, B, Cn, tg.shape[1], 1 if want_grad else 0)
+    ws = torch.empty((max(nws, 16) + 7) // 8, dtype=torch.float64, device=dev)      # torch's caching allocator: stream-ordered, no hipMalloc per call
+    with torch.cuda.device(dev):
+        _lib.check(_lib.lib().mdd_ctc_loss(C.c_void_p(logp.data_ptr()), T, B, Cn, C.c_void_p(tg.data_ptr()), tg.shape[1],
+                                           C.c_void_p(il.data_ptr()), C.c_void_p(tl.data_ptr()), blank,
+                                           C.c_void_p(nll.data_ptr()), C.c_void_p(grad.data_ptr()) if want_grad else None,
+                                           C.c_void_p(ws.data_ptr()), ws.numel() * 8, _lib.current_stream_ptr()))
     return nll, grad

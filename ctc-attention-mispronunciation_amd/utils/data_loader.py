@@ -6,7 +6,9 @@ done on the GPU by mdd_stack_skip) and the zero-padding collate with its float32
 """
 import ctypes as C
 
+import numpy as np
 import torch
+from torch.utils.data import DataLoader, Dataset
 
 from .. import _lib
 
@@ -83,3 +85,58 @@ def create_input(batch):
         lab_sizes[i], trans_sizes[i] = lab.size(0), tr.size(0)
         utts.append(utt)
     return data.float(), in_sizes.float(), label.long(), lab_sizes.long(), trans.long(), trans_sizes.long(), utts
+
+
+class SpeechDataset(Dataset):
+    """Items of one data split: (stacked features [T, (ctx+1)*D], label ids, canonical-transcript ids, utterance id) --
+    AA/utils/data_loader.py:54-146 for the fbank feature type.  ``scp_path``: Kaldi scp of ark offsets, ``lab_path`` /
+    ``trans_path``: '<utt> <phoneme> <phoneme> ...' lines (annotated and canonical phonemes).  With ``train=True`` every
+    item is augmented first (spec_augment on the raw frames, data_enhancement on the canonical ids; :132-137).  The
+    stack / skip / even-pad runs on the host here (numpy, as in the reference's loader workers); batches that are already
+    on the GPU use ``stack_features`` / ``mdd_forward_raw`` instead."""
+
+    def __init__(self, vocab, scp_path, lab_path, trans_path, opts, train=False):
+        self.vocab = vocab
+        self.left_ctx, self.right_ctx = opts.left_ctx, opts.right_ctx
+        self.n_skip_frame, self.n_downsample = opts.n_skip_frame, opts.n_downsample
+        self.train = train
+        unk = vocab.word2index["UNK"]
+
+        def ids(path):
+            table = {}
+            with open(path, "r") as rf:
+                for line in rf:
+                    if line.strip():
+                        utt, text = line.strip().split(" ", 1)
+                        table[utt] = [vocab.word2index.get(c, unk) for c in text.split()]
+            return table
+        paths = []
+        with open(scp_path, "r") as rf:
+            for line in rf:
+                if line.strip():
+                    utt, path = line.strip().split(" ")
+                    paths.append((utt.split(".")[0], path))
+        labels, trans = ids(lab_path), ids(trans_path)
+        assert len(paths) == len(labels) == len(trans)
+        self.item = [(path, labels[utt], trans[utt], utt) for utt, path in paths]
+
+    def __getitem__(self, idx):
+        from .fbank import load_mat
+        from .tools import augment_item, make_context, skip_feat
+        path, label, trans, utt = self.item[idx]
+        feat, trans = augment_item(load_mat(path), trans, train=self.train)
+        feat = skip_feat(make_context(feat, self.left_ctx, self.right_ctx), self.n_skip_frame)
+        if feat.shape[0] % self.n_downsample:
+            feat = np.vstack([feat, np.zeros((self.n_downsample - feat.shape[0] % self.n_downsample, feat.shape[1]))])
+        return torch.from_numpy(feat), torch.LongTensor(label), torch.LongTensor(trans), utt
+
+    def __len__(self):
+        return len(self.item)
+
+
+class SpeechDataLoader(DataLoader):
+    """DataLoader whose collate is ``create_input`` (AA/utils/data_loader.py:191-194)."""
+
+    def __init__(self, *args, **kwargs):
+        super(SpeechDataLoader, self).__init__(*args, **kwargs)
+        self.collate_fn = create_input

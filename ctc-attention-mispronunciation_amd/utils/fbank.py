@@ -105,3 +105,18 @@ def read_ark(ark_path):
         out[key] = np.frombuffer(data, dtype="<f4", count=rows * cols, offset=pos).reshape(rows, cols).copy()
         pos += 4 * rows * cols
     return out
+
+
+def load_mat(spec):
+    """One matrix by its scp entry ``<ark path>:<byte offset>`` (what ``kaldiio.load_mat`` does for the reference's data
+    loader, AA/utils/data_loader.py:130): uncompressed binary float matrices only."""
+    path, _, off = spec.rpartition(":")
+    if not path:
+        raise ValueError("load_mat expects '<ark>:<offset>', got %r" % spec)
+    with open(path, "rb") as f:
+        f.seek(int(off))
+        head = f.read(15)
+        if head[:6] != b"\0BFM \x04"[:6] or head[5:6] != b"\x04" or head[10:11] != b"\x04":
+            raise ValueError("%s: not an uncompressed binary float matrix" % spec)
+        rows, cols = struct.unpack_from("<i", head, 6)[0], struct.unpack_from("<i", head, 11)[0]
+        return np.frombuffer(f.read(4 * rows * cols), dtype="<f4").reshape(rows, cols).copy()

@@ -131,11 +131,16 @@ int mdd_beam(const float *logp_dev, int32_t T, int32_t B, int32_t C, const int32
 
 /* ---- A12: nn.CTCLoss(reduction='sum') pieces (AA/steps/train_ctc.py:72,186): alpha/beta lattice.
  * logp_dev [T,B,C], targets_dev [B,Lmax] int64 (padded), in_len_dev/tgt_len_dev [B] int64 ->
- * nll_dev [B] (per-utterance negative log-likelihood; the reference's loss is their sum) and, if
- * grad_dev != NULL, the tensor autograd deposits on the log-probs: [T,B,C]. */
+ * nll_dev [B] (per-utterance negative log-likelihood; the reference's loss is their sum; +inf for an utterance with no
+ * valid alignment, as the reference gives without zero_infinity) and, if grad_dev != NULL, the tensor autograd deposits
+ * on the log-probs: [T,B,C] (zero on frames >= in_len).  A target label outside [0,C) makes that utterance's nll NaN
+ * and its gradient rows zero (ATen would index past the row).
+ * workspace_dev: caller-owned scratch of at least mdd_ctc_workspace_bytes(T,B,C,Lmax, grad_dev != NULL) bytes (16-byte
+ * aligned; the alpha/beta rows of the backward sweep); NULL = the library allocates stream-ordered for the call. */
+int64_t mdd_ctc_workspace_bytes(int32_t T, int32_t B, int32_t C, int32_t Lmax, int32_t want_grad);
 int mdd_ctc_loss(const float *logp_dev, int32_t T, int32_t B, int32_t C, const int64_t *targets_dev, int32_t Lmax,
                  const int64_t *in_len_dev, const int64_t *tgt_len_dev, int32_t blank, float *nll_dev,
-                 float *grad_dev, void *stream);
+                 float *grad_dev, void *workspace_dev, int64_t workspace_bytes, void *stream);
 
 /* ---- A10: Decoder.wer core = _edit_distance + printChanges (AA/utils/ctcDecoder.py:118-184), host.
  * a = hypothesis tokens, b = canonical tokens; ops (capacity >= na+nb): 0 '-', 1 'S', 2 'I', 3 'D'.

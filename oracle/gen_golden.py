@@ -603,9 +603,76 @@ def gen_chain_goldens():
     json.dump(meta, open(os.path.join(OUT, "g9_chain.json"), "w"))
 
 
+# ----------------------------------------------------------------------------- G10 (augmentation + offline lexicon)
+def gen_aug_goldens():
+    """spec_augment / data_enhancement of AA/utils/tools.py under seeded generators (both numpy's and Python's global RNGs
+    are consumed, in the reference's order), exactly as SpeechDataset.__getitem__ applies them (data_loader.py:132-137);
+    the confusion table the type-2 enhancement draws from is written next to the mirror as data; and the CMU-dictionary
+    lookup of AA/dict/phonetic_dict.py (load_cmudict / cmu_dict, extracted with ast: the module imports TTS / espeak
+    packages that do not exist here) for the words of egs/vocabulary/single, with the stress post-processing of
+    AA/infer.py:543-548."""
+    import random
+    import string
+    json.dump(ref_tools.common_incorrect_voc, open(os.path.join(ROOT, "ctc-attention-mispronunciation_amd", "utils", "common_incorrect_voc.json"), "w"),
+              indent=0, sort_keys=True)
+    arrays, recs = {}, []
+    rs = np.random.Generator(np.random.PCG64(4))
+    for k, (T, D) in enumerate(((37, 81), (60, 81), (6, 81), (50, 40))):
+        feat = rs.standard_normal((T, D)).astype(np.float32)             # kaldiio.load_mat hands float32 matrices
+        trans = [int(v) for v in rs.integers(2, 44, size=int(rs.integers(3, 30)))]
+        for seed in (0, 1, 2):
+            random.seed(100 * k + seed); np.random.seed(100 * k + seed)
+            f2 = ref_tools.spec_augment(feat)                                        # data_loader.py:134
+            t2 = sum([ref_tools.data_enhancement(t) for t in trans], [])             # :136-137
+            arrays["feat%d" % k] = feat
+            arrays["aug%d_%d" % (k, seed)] = f2
+            recs.append(dict(k=k, seed=seed, trans=trans, trans_aug=[int(v) for v in t2]))
+    enh = []
+    for etype in (1, 2, 3, 4):
+        for prob in (0.1, 0.9):
+            random.seed(7 * etype + int(prob * 10))
+            seq = [int(v) for v in np.random.Generator(np.random.PCG64(etype)).integers(2, 44, size=60)]
+            enh.append(dict(type=etype, prob=prob, seed=7 * etype + int(prob * 10), seq=seq,
+                            out=[int(ref_tools.data_enhancement(p, prob, etype)[0]) for p in seq]))
+    # the lexicon: reference methods run on a bare object
+    src = open(os.path.join(AA, "dict", "phonetic_dict.py")).read()
+    cls = [n for n in ast.parse(src).body if isinstance(n, ast.ClassDef) and n.name == "Phonetic"][0]
+    meths = [n for n in cls.body if isinstance(n, ast.FunctionDef) and n.name in ("load_cmudict", "cmu_dict")]
+    stub = ast.ClassDef(name="RefLexicon", bases=[], keywords=[], body=meths, decorator_list=[])
+    ns = {"os": os, "__file__": os.path.join(AA, "dict", "phonetic_dict.py")}
+    exec(compile(ast.fix_missing_locations(ast.Module(body=[stub], type_ignores=[])), "phonetic_dict.py<lexicon>", "exec"), ns)
+    lex = ns["RefLexicon"]()
+    lex.cmudict_plain = {}
+    words = []
+    vdir = "/root/reference/egs/vocabulary/single"
+    for fn in sorted((f for f in os.listdir(vdir) if f.endswith(".txt")), key=lambda f: int(f.split(".")[0])):
+        words.append(open(os.path.join(vdir, fn)).read().strip())
+    words += ["The", "READ", "tomato", "zzzznotaword"]
+    lexrec = []
+    keep = set()
+    for w_ in words:
+        p1 = lex.cmu_dict(w_)
+        model = None
+        if p1:
+            parts_ = [p.rstrip(string.digits) if p not in ["ER0", "AH0"] else p for p in p1.split(" ")]     # infer.py:545-547
+            model = " ".join(p.lower() for p in parts_)
+            keep.add(w_.lower())
+        lexrec.append(dict(word=w_, cmu=p1, model=model))
+    # data fixture: the dictionary lines of those words (and their alternates, which follow the reference's last-one-wins load)
+    with open(os.path.join(AA, "dict", "cmudict.dict")) as f, open(os.path.join(OUT, "cmudict_subset.dict"), "w") as o:
+        for line in f:
+            key = line.split(" ")[0].strip().lower()
+            if key in keep or key.split("(")[0] in keep:
+                o.write(line)
+    np.savez_compressed(os.path.join(OUT, "g10_aug.npz"), **arrays)
+    json.dump(dict(items=recs, enhancement=enh, lexicon=lexrec, vowels=ref_tools.vowels, consonants=ref_tools.consonants),
+              open(os.path.join(OUT, "g10_aug.json"), "w"))
+    print("G10 aug: %d items, %d enhancement runs, lexicon:" % (len(recs), len(enh)), [(r["word"], r["model"]) for r in lexrec[:4]], "...")
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ["model", "decode", "align", "eval", "ctc", "input", "chain"]
+    which = sys.argv[1:] or ["model", "decode", "align", "eval", "ctc", "input", "chain", "aug"]
     with torch.no_grad():
         if "model" in which:
             gen_model_goldens()
@@ -621,3 +688,5 @@ if __name__ == "__main__":
         gen_input_goldens()
     if "chain" in which:
         gen_chain_goldens()
+    if "aug" in which:
+        gen_aug_goldens()

@@ -587,3 +587,61 @@ def test_bench_two_ranks_rehearsal():
     assert out["n_gpus"] == 2 and out["steps"] == 2 and out["scaling"] == "weak" and out["value"] > 0
     assert out["config"]["global_batch"] == 128 and "all-gather" in out["config"]["parallelism"]
     assert out["gather_verified"] is True
+
+
+@pytest.mark.parametrize("L,T,B", [(40, 250, 8), (100, 300, 3), (200, 420, 2), (63, 130, 4), (64, 130, 4), (1, 5, 3)])
+def test_ctc_wave_kernel_label_widths_against_oracle(L, T, B, monkeypatch):
+    """The wavefront lattice kernel at 1, 2 and 4 labels per lane (Lmax <= 63 / 127 / 255), ragged input and label lengths,
+    repeated labels: against the fp64 oracle, against the generic (one-thread-per-state) kernel, and bit-identical from run
+    to run (the per-class sums use no atomics)."""
+    rs = np.random.Generator(np.random.PCG64(L * 1000 + T))
+    Cn = 45
+    lp = torch.log_softmax(torch.from_numpy((rs.standard_normal((T, B, Cn)) * 2.0).astype(np.float32)), -1).numpy()
+    tg = rs.integers(1, Cn, size=(B, L))
+    if L > 2:
+        tg[:, 1] = tg[:, 0]                                   # repeats: a blank is forced between them
+    tl = rs.integers(max(1, L // 2), L + 1, size=B); tl[0] = L
+    il = np.array([min(T, max(int(rs.integers(T // 2, T + 1)), 2 * int(tl[b]) + 2)) for b in range(B)]); il[0] = T
+    nll, grad = _hip().ctc_loss(_cuda(lp), _cuda(tg), _cuda(il), _cuda(tl))
+    onll, ograd = oracle.ctc_loss(lp, tg, il, tl)
+    assert np.isfinite(onll).all()
+    np.testing.assert_allclose(nll.cpu().numpy(), onll, rtol=1e-6)
+    np.testing.assert_allclose(grad.cpu().numpy(), ograd, rtol=0, atol=5e-6)
+    nll2, grad2 = _hip().ctc_loss(_cuda(lp), _cuda(tg), _cuda(il), _cuda(tl))
+    assert torch.equal(nll, nll2) and torch.equal(grad, grad2)
+    monkeypatch.setenv("MDD_CTC", "generic")
+    nll3, grad3 = _hip().ctc_loss(_cuda(lp), _cuda(tg), _cuda(il), _cuda(tl))
+    np.testing.assert_allclose(nll3.cpu().numpy(), onll, rtol=1e-6)
+    np.testing.assert_allclose(grad3.cpu().numpy(), ograd, rtol=0, atol=2e-6)
+
+
+def test_ctc_bad_labels_infeasible_rows_and_workspace_contract():
+    import ctypes as C
+    from ctc_attention_mispronunciation_amd import _lib
+    rs = np.random.Generator(np.random.PCG64(3))
+    T, B, Cn, L = 20, 4, 9, 5
+    lp = torch.log_softmax(torch.from_numpy(rs.standard_normal((T, B, Cn)).astype(np.float32)), -1).numpy()
+    tg = rs.integers(1, Cn, size=(B, L))
+    tg[1, 2] = Cn            # label outside [0, C): NaN for that utterance, zero gradient rows, nothing read out of bounds
+    tg[2, 0] = -3
+    il = np.array([T, T, T, 3]); tl = np.array([L, L, L, L])          # row 3: 5 labels cannot fit 3 frames -> +inf (reference: inf)
+    nll, grad = _hip().ctc_loss(_cuda(lp), _cuda(tg), _cuda(il), _cuda(tl))
+    nll, grad = nll.cpu().numpy(), grad.cpu().numpy()
+    assert np.isfinite(nll[0]) and np.isnan(nll[1]) and np.isnan(nll[2]) and np.isposinf(nll[3])
+    assert not grad[:, 1].any() and not grad[:, 2].any() and not grad[3:, 3].any()
+    ref = torch.nn.CTCLoss(reduction="none")(torch.from_numpy(lp), torch.from_numpy(np.clip(tg, 1, Cn - 1)), torch.from_numpy(il), torch.from_numpy(tl)).numpy()
+    np.testing.assert_allclose(nll[0], ref[0], rtol=1e-5)
+    assert np.isposinf(ref[3])
+    # a caller workspace that is too small is refused, not overrun
+    L_ = _lib.lib()
+    need = L_.mdd_ctc_workspace_bytes(T, B, Cn, L, 1)
+    assert need > 0 and L_.mdd_ctc_workspace_bytes(T, B, Cn, L, 0) == 0
+    small = torch.empty(need // 8 - 1, dtype=torch.float64, device="cuda")
+    lpd, tgd, ild, tld = _cuda(lp), _cuda(np.clip(tg, 1, Cn - 1)), _cuda(il), _cuda(tl)
+    out_n = torch.empty(B, device="cuda"); out_g = torch.empty((T, B, Cn), device="cuda")
+    args = [C.c_void_p(lpd.data_ptr()), T, B, Cn, C.c_void_p(tgd.data_ptr()), L, C.c_void_p(ild.data_ptr()), C.c_void_p(tld.data_ptr()), 0,
+            C.c_void_p(out_n.data_ptr()), C.c_void_p(out_g.data_ptr())]
+    assert L_.mdd_ctc_loss(*args, C.c_void_p(small.data_ptr()), small.numel() * 8, None) == -1
+    assert L_.mdd_ctc_loss(*args, None, 0, None) == 0                  # no workspace: the library allocates stream-ordered
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(out_n.cpu().numpy()[:3], ref[:3], rtol=1e-5)

@@ -117,3 +117,80 @@ def test_product_path_has_no_cpu_fallback():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 src = open(os.path.join(dirpath, f)).read()
                 assert "liboracle" not in src and "import oracle" not in src and "from oracle" not in src, f
+
+
+def test_augmentation_goldens_reproduce_the_reference_rng_stream():
+    """spec_augment + data_enhancement (AA/utils/tools.py:229-255,290-359) as the data loader applies them
+    to a training item (data_loader.py:132-137).  Both global generators (numpy's for mask widths, Python's for positions
+    and mutations) are consumed in the reference's order, so seeded runs give the reference's outputs exactly (G10)."""
+    import random
+    from ctc_attention_mispronunciation_amd.utils import tools
+    g, meta = npz("g10_aug.npz"), jload("g10_aug.json")
+    assert tools.vowels == meta["vowels"] and tools.consonants == meta["consonants"]
+    for r in meta["items"]:
+        feat = g["feat%d" % r["k"]]
+        random.seed(100 * r["k"] + r["seed"]); np.random.seed(100 * r["k"] + r["seed"])
+        f2, t2 = tools.augment_item(feat, r["trans"], train=True)
+        np.testing.assert_array_equal(f2, g["aug%d_%d" % (r["k"], r["seed"])])
+        assert f2.dtype == feat.dtype and t2 == r["trans_aug"]
+        f3, t3 = tools.augment_item(feat, r["trans"], train=False)
+        assert f3 is feat and t3 == r["trans"]
+    for e in meta["enhancement"]:
+        random.seed(e["seed"])
+        assert [tools.data_enhancement(p, e["prob"], e["type"])[0] for p in e["seq"]] == e["out"], (e["type"], e["prob"])
+    # the host forms of stack / skip agree with the GPU path's golden (G6)
+    g6 = npz("g6_input.npz")
+    for i in range(6):
+        st = tools.skip_feat(tools.make_context(g6["raw%d" % i], 0, 2), 2)
+        if st.shape[0] % 2:
+            st = np.vstack([st, np.zeros((1, st.shape[1]), dtype=st.dtype)])
+        np.testing.assert_array_equal(st.astype(np.float32), g6["stk%d" % i])
+
+
+def test_offline_lexicon_matches_reference_cmudict_lookup():
+    """Word -> canonical phonemes without espeak / g2p_en / MeloTTS: the reference's own load_cmudict / cmu_dict answers
+    for the words of egs/vocabulary/single (G10), then the stress handling of infer.py:543-548."""
+    from ctc_attention_mispronunciation_amd.dict.phonetic_dict import Phonetic
+    ph = Phonetic(os.path.join(GOLD, "cmudict_subset.dict"))
+    for r in jload("g10_aug.json")["lexicon"]:
+        assert ph.cmu_dict(r["word"]) == r["cmu"], r
+        assert ph.api_word_phones_cmu(r["word"] + "\n") == r["cmu"]
+        if r["cmu"]:
+            assert Phonetic.phones_for_model(r["cmu"]) == r["model"]
+    assert ph.cmu_dict("zzzznotaword") is None
+    with pytest.raises(FileNotFoundError):
+        Phonetic("/nonexistent/cmudict.dict").cmu_dict("a")
+
+
+def test_speech_dataset_reads_ark_and_collates(tmp_path):
+    """SpeechDataset / SpeechDataLoader over a Kaldi ark+scp written by the package's own writer: eval items are the stacked
+    rows of the G6 golden arithmetic, train items are augmented, batches come out of create_input."""
+    import random
+    import types
+    import torch
+    from ctc_attention_mispronunciation_amd.utils import data_loader as dl, fbank as fb, tools
+    rs = np.random.Generator(np.random.PCG64(2))
+    feats = {"u%d" % i: rs.standard_normal((9 + 4 * i, 81)).astype(np.float32) for i in range(3)}
+    # fbank's writer needs no GPU; it writes the scp index with byte offsets
+    fb.write_ark_scp(str(tmp_path / "f.ark"), str(tmp_path / "f.scp"), feats)
+    (tmp_path / "units").write_text("\n".join("%s %s" % (p, p) for p in "sil aa b k".split()) + "\n")
+    (tmp_path / "lab").write_text("u0 aa b\nu1 k zz aa\nu2 b\n")
+    (tmp_path / "trn").write_text("u0 aa k\nu1 k b aa\nu2 sil b\n")
+    vocab = dl.Vocab(str(tmp_path / "units"))
+    opts = types.SimpleNamespace(left_ctx=0, right_ctx=2, n_skip_frame=2, n_downsample=2, feature_type="fbank", mel=False)
+    ds = dl.SpeechDataset(vocab, str(tmp_path / "f.scp"), str(tmp_path / "lab"), str(tmp_path / "trn"), opts, train=False)
+    assert len(ds) == 3
+    x, lab, tr, utt = ds[1]
+    want = tools.skip_feat(tools.make_context(feats["u1"], 0, 2), 2)
+    assert utt == "u1" and x.shape == (8, 243) and lab.tolist() == [vocab.word2index["k"], 1, vocab.word2index["aa"]]
+    np.testing.assert_array_equal(x.numpy()[:7], want)
+    assert not x.numpy()[7].any()                                   # 13 frames -> 7 kept -> padded to 8
+    batch = next(iter(dl.SpeechDataLoader(ds, batch_size=3, shuffle=False)))
+    assert batch[0].shape == (3, 10, 243) and batch[0].dtype == torch.float32 and batch[6] == ["u0", "u1", "u2"]
+    np.testing.assert_allclose(batch[1].numpy(), np.array([6, 8, 10], dtype=np.float32) / np.float32(10))
+    tr_ds = dl.SpeechDataset(vocab, str(tmp_path / "f.scp"), str(tmp_path / "lab"), str(tmp_path / "trn"), opts, train=True)
+    random.seed(3); np.random.seed(3)
+    xa = tr_ds[2][0]
+    random.seed(3); np.random.seed(3)
+    f2, _ = tools.augment_item(feats["u2"], [2, 4], train=True)
+    np.testing.assert_array_equal(xa.numpy()[:9], tools.skip_feat(tools.make_context(f2, 0, 2), 2))
