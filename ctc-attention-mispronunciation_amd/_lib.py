@@ -16,6 +16,8 @@ EXPORTS = (
     "mdd_last_error", "mdd_version", "mdd_create", "mdd_destroy", "mdd_load_weight", "mdd_finalize_weights",
     "mdd_set_precision", "mdd_get_precision", "mdd_stack_len", "mdd_stack_skip", "mdd_len_frames", "mdd_forward", "mdd_forward_raw", "mdd_forward_num_stages", "mdd_forward_profile", "mdd_tap", "mdd_tap_copy", "mdd_enable_taps", "mdd_sync",
     "mdd_greedy", "mdd_beam", "mdd_ctc_loss", "mdd_ctc_workspace_bytes", "mdd_align", "mdd_align_batch", "mdd_eval_batch", "mdd_fbank_num_frames", "mdd_fbank",
+    "mdd_train_create", "mdd_train_destroy", "mdd_train_num_tensors", "mdd_train_tensor_info", "mdd_train_num_masks", "mdd_train_mask_bytes",
+    "mdd_train_forward", "mdd_train_backward", "mdd_train_sync", "mdd_adam_step",
     "mdd_diag_gemm", "mdd_diag_gemm_ph8",
 )
 
@@ -78,6 +80,18 @@ def lib():
     L.mdd_fbank_num_frames.argtypes = [C.c_int64]
     L.mdd_fbank_num_frames.restype = i32
     L.mdd_fbank.argtypes = [vp, C.c_int64, vp, vp, vp, vp]
+    L.mdd_train_create.argtypes = [C.POINTER(MddConfig), C.c_int, C.POINTER(vp)]
+    L.mdd_train_destroy.argtypes = [vp]
+    L.mdd_train_destroy.restype = None
+    L.mdd_train_num_tensors.argtypes = [vp]
+    L.mdd_train_tensor_info.argtypes = [vp, i32, C.c_char_p, i32, i64p, C.POINTER(i32)]
+    L.mdd_train_num_masks.argtypes = [vp]
+    L.mdd_train_mask_bytes.argtypes = [vp, i32, i32, i32]
+    L.mdd_train_mask_bytes.restype = C.c_int64
+    L.mdd_train_forward.argtypes = [vp, vp, vp, i32, i32, vp, i32, vp, C.c_uint64, C.c_float, vp, vp]
+    L.mdd_train_backward.argtypes = [vp, vp, vp, vp, vp]
+    L.mdd_train_sync.argtypes = [vp, vp]
+    L.mdd_adam_step.argtypes = [vp, vp, vp, vp, vp, i32, i32, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, vp]
     _lib = L
     return L
 

@@ -72,6 +72,11 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(LstmStepArgs a, int s) {
         const float hn = og * tanhf(cn);
         a.cbuf[ci] = cn;
         hnext[(size_t)b * H + u] = hn;
+        if (a.gates_save) {   // train mode: what the backward sweep needs (train_kernels.hip)
+            const size_t si = (((size_t)t * B + b) * 2 + d) * H + u;
+            *reinterpret_cast<float4 *>(a.gates_save + si * 4) = make_float4(ig, fg, gg, og);
+            a.c_save[si] = cn;
+        }
         const size_t oi = ((size_t)t * B + b) * 2 * H + d * H + u;
         if (a.out_raw) a.out_raw[oi] = hn;
         const float ov = a.oscale ? hn * a.oscale[d * H + u] + a.oshift[d * H + u] : hn;
@@ -989,6 +994,17 @@ int init_persistent_attributes() {
 #define PATTR(H, N) MDD_HIP_CHECK(hipFuncSetAttribute((const void *)lstm_layer_persistent_kernel<H, N>, hipFuncAttributeMaxDynamicSharedMemorySize, 112 * 1024))
     PATTR(384, 1); PATTR(384, 2); PATTR(384, 4); PATTR(256, 1); PATTR(256, 2); PATTR(256, 4);
 #undef PATTR
+    return MDD_OK;
+}
+
+int launch_lstm_layer_train(const LstmStepArgs &a, hipStream_t st) {
+    if (a.H % 4 != 0 || a.T <= 0 || a.B <= 0 || a.packed || a.hsplit) { set_error("lstm (train): bad arguments T=%d B=%d H=%d", a.T, a.B, a.H); return MDD_ERR_ARG; }
+    dim3 grid(a.H / 4, 2, (a.B + 63) / 64), block(256);
+    for (int s = 0; s < a.T; s++) {
+        if (a.H % 16 == 0) hipLaunchKernelGGL(lstm_step_kernel<true>, grid, block, 0, st, a, s);
+        else hipLaunchKernelGGL(lstm_step_kernel<false>, grid, block, 0, st, a, s);
+    }
+    MDD_LAUNCH_CHECK();
     return MDD_OK;
 }
 

@@ -33,6 +33,10 @@ struct SplitPtr { unsigned short *hi, *lo; };
 int launch_gemm_nt(const float *A, const float *W, const float *bias, float *C, int M, int N, int K, int lda, int ldw,
                    int ldc, int batch, long sA, long sW, long sC, hipStream_t st);
 
+// General fp32 GEMM (training step): C[m,n] (+)= sum_k opA[m,k] opB[n,k]; ta / tb: the operand is stored [K, rows] (see gemm.hip)
+int launch_gemm_f32(bool ta, bool tb, const float *A, const float *B, const float *bias, float *C, int M, int N, int K, int lda, int ldb,
+                    int ldc, int batch, long sA, long sB, long sC, bool accumulate, hipStream_t st, int ksplit = 0);
+
 // C = A . W^T on the bf16 matrix cores with split-bf16 operands (see gemm_bf16x3.hip).  Output fp32 C, or a
 // split-bf16 tensor when Csplit != nullptr.  K % 32 == 0, ld* % 8 == 0.
 int launch_gemm_bf16x3(const SplitPtr &A, const SplitPtr &W, const float *bias, float *C, const SplitPtr *Csplit, int M, int N,
@@ -69,6 +73,8 @@ struct LstmStepArgs {
     SplitPtr whh_split;  // row-major Whh' [2][4H][H] as hi/lo planes (split-bf16 step only)
     unsigned short *hsplit;  // h exchange of the split-bf16 step: [2 parity][hi|lo][2 dir][B][H]; null selects the fp32 steps
     int packed;          // 1: whh / hbuf / cbuf use the packed consumer layouts of lstm_step_packed_kernel
+    float *gates_save = nullptr;   // train mode (generic step kernel only): [T][B][2][H][4] post-activation i,f,g,o
+    float *c_save = nullptr;       //                                          [T][B][2][H]    cell state
 };
 // Enqueue all T steps of one bidirectional layer.
 int launch_lstm_layer(const LstmStepArgs &a, hipStream_t st);

@@ -108,7 +108,7 @@ class CTC_Model(nn.Module):
         self._handle = None
         self._dirty = True
         self.strict_errors = True   # raise IndexError for bad canonical ids synchronously, like nn.Embedding
-        self.eval_only_reason = "the MI355X path implements eval-mode forward (BatchNorm running stats, no dropout)"
+        self._dropout_masks = None  # tests: the reference's own dropout masks (one uint8 tensor per site, mdd_hip.h); None = drawn
 
     # ------------------------------------------------------------------ library plumbing
     def _check_supported(self):
@@ -188,9 +188,12 @@ class CTC_Model(nn.Module):
         if not self.add_cnn:
             print("error")          # model_ctc.py:224-225
             return None
-        if self.training:
-            raise NotImplementedError(self.eval_only_reason)
         _lib.require_gpu()
+        if self.training:      # BatchNorm on batch statistics, Dropout(drop_out) behind each LayerCNN / BatchRNN; differentiable
+            if visualize:
+                raise NotImplementedError("visualize=True is an eval-mode facility here")
+            from ..train import model_forward_train
+            return model_forward_train(self, x, x1, masks=getattr(self, "_dropout_masks", None))
         src_device = x.device
         dev = x.device if x.is_cuda else torch.device("cuda", torch.cuda.current_device())
         xd = x.to(dev, torch.float32).contiguous()

@@ -121,6 +121,25 @@ def synth_batch(geom, B, T, L, seed=1234, ragged=True):
     return x, x1, frac, tlen
 
 
+def train_case(geom, seed, B, T, L, Lt, p=0.2):
+    """Inputs of one training step (G11 goldens and their tests): seeded weights, batch, one dropout mask per site in the
+    reference's tensor layout (1 = keep), padded CTC targets and feasible input lengths ((frac * T').long(), train_ctc.py:68)."""
+    sd = synth_state_dict(geom, seed=seed)
+    x, x1, frac, _ = synth_batch(geom, B=B, T=T, L=L, seed=seed)
+    rs = np.random.Generator(np.random.PCG64(seed + 5))
+    Tp = T // 2
+    shapes = [(B, geom.channels, T, geom.w1), (B, geom.channels, Tp, geom.w2)] + [(Tp, B, 2 * geom.hidden)] * geom.layers
+    masks = [(rs.random(s) >= p).astype(np.uint8) for s in shapes]
+    tl = rs.integers(1, Lt + 1, size=B)
+    tl[0] = Lt
+    tg = np.zeros((B, Lt), dtype=np.int64)
+    for b in range(B):
+        tg[b, :tl[b]] = rs.integers(1, geom.num_class, size=tl[b])
+    il = (frac.astype(np.float32) * np.float32(Tp)).astype(np.int64)
+    il = np.minimum(np.maximum(il, 2 * tl + 1), Tp)                      # keep every row feasible
+    return sd, x, x1, masks, tg, il.astype(np.int64), tl.astype(np.int64)
+
+
 def synth_raw_features(B, T_raw=1000, D=81, seed=1234):
     """Raw (CMVN-scale) log-mel + energy frames, N(0,1) f32."""
     rng = np.random.Generator(np.random.PCG64(seed + 29))

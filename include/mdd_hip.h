@@ -173,6 +173,36 @@ int mdd_fbank(const float *wav_dev, int64_t n_samples, const float *cmvn_scale_d
 int mdd_eval_batch(const int32_t *dec, const int32_t *dec_len, const int32_t *lab, const int32_t *lab_len,
                    const int32_t *can, const int32_t *can_len, int32_t n, int32_t stride, int64_t *counts);
 
+/* ---- SURVEY 8(f) #3 / BASELINE config 5: one training step of run_epoch (AA/steps/train_ctc.py:28-105).
+ * The drop-in CTC_Model keeps its parameters as torch tensors; every call receives their device pointers.
+ *   mdd_train_create            geometry as mdd_create; the handle owns the activations saved between forward and backward
+ *   mdd_train_tensor_info       key / element count / "is a BatchNorm running-statistics buffer" of tensor i: the 55 float entries
+ *                               of CTC_Model.state_dict() (AA/models/model_ctc.py:84-158), in state_dict order
+ *   mdd_train_forward           CTC_Model.forward in TRAIN mode (model_ctc.py:160-223): BatchNorm on batch statistics (biased
+ *                               variance; running statistics updated in place with momentum 0.1 and the unbiased variance),
+ *                               Dropout(p_drop) behind each LayerCNN and BatchRNN.  masks: NULL (masks drawn from `seed` by a
+ *                               counter-based generator) or mdd_train_num_masks() device byte arrays (1 = keep) laid out like the
+ *                               reference's tensor at that site -- [B,ch,T,W1], [B,ch,T/2,W2], then [T/2,B,2H] per BatchRNN --
+ *                               of mdd_train_mask_bytes() bytes each.  x_dev / x1_dev must stay valid until the backward call.
+ *   mdd_train_backward          autograd's backward of that forward: dlogp_dev [T/2,B,C] (e.g. mdd_ctc_loss's gradient scaled
+ *                               by 1/B as train_ctc.py:73-74 divides the loss) -> one gradient per parameter into grads[i]
+ *                               (entries of running-statistics buffers are ignored and may be NULL)
+ *   mdd_adam_step               torch.optim.Adam over n tensors (train_ctc.py:187: lr 1e-3, weight_decay 5e-4 added to the gradient)
+ * Arithmetic is exact fp32 (v_mfma_f32_*), as the reference trains. */
+typedef struct mdd_train_ws mdd_train_ws;
+int mdd_train_create(const mdd_config *cfg, int device, mdd_train_ws **out);
+void mdd_train_destroy(mdd_train_ws *w);
+int32_t mdd_train_num_tensors(mdd_train_ws *w);
+int mdd_train_tensor_info(mdd_train_ws *w, int32_t i, char *key, int32_t cap, int64_t *numel, int32_t *is_buffer);
+int32_t mdd_train_num_masks(mdd_train_ws *w);
+int64_t mdd_train_mask_bytes(mdd_train_ws *w, int32_t site, int32_t B, int32_t T);
+int mdd_train_forward(mdd_train_ws *w, float *const *tensors, const float *x_dev, int32_t B, int32_t T, const int64_t *x1_dev, int32_t L,
+                      const uint8_t *const *masks, uint64_t seed, float p_drop, float *logp_dev, void *stream);
+int mdd_train_backward(mdd_train_ws *w, float *const *tensors, const float *dlogp_dev, float *const *grads, void *stream);
+int mdd_train_sync(mdd_train_ws *w, void *stream);
+int mdd_adam_step(float *const *params, float *const *grads, float *const *exp_avg, float *const *exp_avg_sq, const int64_t *numel, int32_t n,
+                  int32_t step, float lr, float beta1, float beta2, float eps, float weight_decay, void *stream);
+
 /* ---- Diagnostics (test and measurement aids; no reference counterpart).
  * mdd_diag_gemm: time one launch form of the split-bf16 projection GEMM on constant operands (abl selects the form;
  * tools/gemm_*.py).  mdd_diag_gemm_ph8: race screen of the 8-phase GEMM -- the same pseudo-random operands through the

@@ -670,9 +670,60 @@ def gen_aug_goldens():
     print("G10 aug: %d items, %d enhancement runs, lexicon:" % (len(recs), len(enh)), [(r["word"], r["model"]) for r in lexrec[:4]], "...")
 
 
+# ----------------------------------------------------------------------------- G11 (one training step)
+class GivenDropout(nn.Module):
+    """nn.Dropout with the mask handed in: y = x * (mask / (1-p)), the arithmetic of ATen's dropout with a fixed noise tensor."""
+
+    def __init__(self, mask, p):
+        super(GivenDropout, self).__init__()
+        self.noise = torch.from_numpy(mask.astype(np.float32)) * (1.0 / (1.0 - p))
+
+    def forward(self, x):
+        return x * self.noise
+
+
+def gen_train_goldens():
+    """The REFERENCE model in train mode (BatchNorm on batch statistics, its Dropout modules replaced by GivenDropout with seeded
+    masks), loss = nn.CTCLoss(sum)(out, targets, in_len, tgt_len) / B, loss.backward()  (AA/steps/train_ctc.py:63-76):
+    log-probs, loss, every parameter gradient and the updated running statistics.  Tiny geometry in full; reference geometry
+    (H=384, 4 layers) as norms + 48 sampled entries per tensor (the tensors have 21 M elements)."""
+    arrays, meta = {}, []
+    for tag, g, seed, B, T, L, Lt in (("tiny", dict(synth.TINY), 11, 3, 12, 4, 2), ("ref", dict(synth.REFERENCE), 21, 2, 16, 5, 3)):
+        geom = synth.Geometry(**g)
+        sd, x, x1, masks, tg, il, tl = synth.train_case(geom, seed, B, T, L, Lt)
+        m = build_reference_model(geom, sd)
+        m.train()
+        drops = [m.conv[0], m.conv[1]] + [m.rnns[i] for i in range(geom.layers)]
+        for mod, mk in zip(drops, masks):
+            assert isinstance(mod.dropout, nn.Dropout) and abs(mod.dropout.p - 0.2) < 1e-12
+            mod.dropout = GivenDropout(mk, 0.2)
+        out = m(torch.from_numpy(x), torch.from_numpy(x1))
+        loss = nn.CTCLoss(reduction="sum")(out, torch.from_numpy(tg), torch.from_numpy(il), torch.from_numpy(tl)) / B
+        loss.backward()
+        rec = dict(tag=tag, geom=g, seed=seed, B=B, T=T, L=L, Lt=Lt, loss=float(loss.item()), tensors={})
+        arrays[tag + "_logp"] = out.detach().numpy()
+        rs = np.random.Generator(np.random.PCG64(99))
+        for k, prm in m.named_parameters():
+            gr = prm.grad.numpy().ravel()
+            if tag == "tiny" or gr.size <= 4096:
+                arrays["%s_grad_%s" % (tag, k)] = prm.grad.numpy()
+            else:
+                idx_ = rs.integers(0, gr.size, size=48)
+                arrays["%s_gidx_%s" % (tag, k)] = idx_
+                arrays["%s_gval_%s" % (tag, k)] = gr[idx_]
+            rec["tensors"][k] = dict(norm=float(np.sqrt((gr.astype(np.float64) ** 2).sum())), absmax=float(np.abs(gr).max()))
+        for k, bufv in m.named_buffers():
+            if "running_" in k:
+                arrays["%s_run_%s" % (tag, k)] = bufv.numpy().copy()
+        meta.append(rec)
+        print("G11", tag, "loss %.6f" % rec["loss"], "grad norms fc.1 %.3e conv.0 %.3e" % (rec["tensors"]["fc.1.weight"]["norm"], rec["tensors"]["conv.0.conv.weight"]["norm"]))
+    np.savez_compressed(os.path.join(OUT, "g11_train.npz"), **arrays)
+    json.dump(meta, open(os.path.join(OUT, "g11_train.json"), "w"))
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ["model", "decode", "align", "eval", "ctc", "input", "chain", "aug"]
+    which = sys.argv[1:] or ["model", "decode", "align", "eval", "ctc", "input", "chain", "aug", "train"]
     with torch.no_grad():
         if "model" in which:
             gen_model_goldens()
@@ -690,3 +741,5 @@ if __name__ == "__main__":
         gen_chain_goldens()
     if "aug" in which:
         gen_aug_goldens()
+    if "train" in which:
+        gen_train_goldens()

@@ -13,6 +13,7 @@ AA/utils/BeamSearch.py:43-153.
 """
 import math
 
+import numpy as np
 import torch
 import torch.nn.functional as F
 
@@ -125,3 +126,56 @@ def beam(logp, lens, int2char, lm, beam_width=10, alpha=0.0, blank=0):
         best = sorted(final, key=lambda v: v[0], reverse=True)[0][1]
         out.append(" ".join(int2char[k] for k in best))
     return out
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# Train-mode restatement (torch autograd on ATen CPU ops) -- the checker of the HIP training step on shapes that have no
+# golden: CTC_Model.forward with BatchNorm on batch statistics and Dropout realised by GIVEN masks (1 = keep; the kept values are
+# scaled by 1/(1-p), as nn.Dropout does), nn.CTCLoss(sum)/B, backward.  Pinned against the real reference by tests/golden/g11_*.
+def train_step(sd_np, x, x1, masks, targets, in_len, tgt_len, p_drop, momentum=0.1, eps=1e-5):
+    """Returns (logp [T',B,C], loss, {key: grad}, {running-stat key: updated value}).  masks: list of arrays in the reference's
+    layouts: [B,ch,T,W1], [B,ch,T',W2], then [T',B,2H] per BatchRNN layer."""
+    sd = {k: torch.tensor(v, dtype=torch.float32) for k, v in sd_np.items() if np.asarray(v).dtype.kind == "f"}
+    params = {k: v.requires_grad_(True) for k, v in sd.items() if "running_" not in k}
+    run = {k: v.clone() for k, v in sd.items() if "running_" in k}
+    scale = 1.0 / (1.0 - p_drop)
+
+    def bn(t, prefix):       # t: [N, C, ...], training=True updates the running statistics in place
+        return F.batch_norm(t, run[prefix + ".running_mean"], run[prefix + ".running_var"], params[prefix + ".weight"], params[prefix + ".bias"],
+                            training=True, momentum=momentum, eps=eps)
+
+    def drop(t, m):
+        return t * (torch.as_tensor(m, dtype=torch.float32) * scale) if p_drop > 0 else t
+
+    def bilstm(t, prefix, bias, batch_first=False):
+        H = params[prefix + ".weight_hh_l0"].shape[1]
+        names = ["weight_ih_l0", "weight_hh_l0"] + (["bias_ih_l0", "bias_hh_l0"] if bias else [])
+        flat = [params["%s.%s%s" % (prefix, n, sfx)] for sfx in ("", "_reverse") for n in names]
+        h0 = t.new_zeros(2, t.shape[0] if batch_first else t.shape[1], H)
+        out, _, _ = torch._VF.lstm(t, (h0, h0.clone()), flat, bias, 1, 0.0, True, True, batch_first)
+        return out
+
+    a = torch.as_tensor(x, dtype=torch.float32).unsqueeze(1)
+    for n, stride in ((0, (1, 2)), (1, (2, 2))):
+        a = F.conv2d(a, params["conv.%d.conv.weight" % n], params["conv.%d.conv.bias" % n], stride=stride, padding=(1, 1))
+        a = drop(F.relu(bn(a, "conv.%d.batch_norm" % n)), masks[n])
+    B, C_, T, W = a.shape
+    seq = a.transpose(1, 2).contiguous().view(B, T, C_ * W).transpose(0, 1).contiguous()
+    n = 0
+    while "rnns.%d.rnn.weight_ih_l0" % n in params:
+        if n > 0:
+            seq = bn(seq.transpose(-1, -2), "rnns.%d.batch_norm" % n).transpose(-1, -2)
+        seq = drop(bilstm(seq, "rnns.%d.rnn" % n, bias=False), masks[2 + n])
+        n += 1
+    X = seq.transpose(0, 1)
+    val = bilstm(F.embedding(torch.as_tensor(x1, dtype=torch.int64), params["embeds.weight"]), "lstm_embeds", bias=True, batch_first=True)
+    key = F.linear(val, params["score.weight"])
+    attn = torch.softmax(torch.bmm(X, key.transpose(1, 2)), dim=-1)
+    cat = torch.cat((X, torch.bmm(attn, val)), -1).transpose(0, 1).contiguous()
+    Tp = cat.shape[0]
+    logits = F.linear(bn(cat.view(Tp * B, -1), "fc.0"), params["fc.1.weight"])
+    logp = torch.log_softmax(logits.view(Tp, B, -1), dim=-1)
+    loss = F.ctc_loss(logp, torch.as_tensor(targets, dtype=torch.int64), torch.as_tensor(in_len, dtype=torch.int64),
+                      torch.as_tensor(tgt_len, dtype=torch.int64), blank=0, reduction="sum") / B       # train_ctc.py:72-74
+    loss.backward()
+    return (logp.detach().numpy(), float(loss.item()), {k: v.grad.numpy() for k, v in params.items()}, {k: v.numpy() for k, v in run.items()})

@@ -94,9 +94,6 @@ def test_dropin_class_matches_golden_and_reference_api():
     bad[0, 0] = 44                                                               # 'err' cannot be embedded (model_ctc.py:149)
     with pytest.raises(IndexError):
         model(torch.from_numpy(x), bad)
-    model.train()
-    with pytest.raises(NotImplementedError):
-        model(torch.from_numpy(x), torch.from_numpy(x1))
 
 
 @pytest.mark.parametrize("precision", ["f32", "bf16x3"])
@@ -645,3 +642,173 @@ def test_ctc_bad_labels_infeasible_rows_and_workspace_contract():
     assert L_.mdd_ctc_loss(*args, None, 0, None) == 0                  # no workspace: the library allocates stream-ordered
     torch.cuda.synchronize()
     np.testing.assert_allclose(out_n.cpu().numpy()[:3], ref[:3], rtol=1e-5)
+
+
+# ---------------------------------------------------------------------------- training step (BASELINE config 5)
+def _train_model(geom, sd):
+    import torch.nn as nn
+    from ctc_attention_mispronunciation_amd.models.model_ctc import CTC_Model
+    model = CTC_Model(add_cnn=True, cnn_param=geom.cnn_param(nn), rnn_param=geom.rnn_param(nn), num_class=geom.num_class, drop_out=0.2)
+    if geom.emb_rows != 44 or geom.emb_dim != 512:          # tiny geometry (as oracle/gen_golden.py builds the reference)
+        model.embeds = nn.Embedding(geom.emb_rows, geom.emb_dim)
+        model.lstm_embeds = nn.LSTM(geom.emb_dim, geom.hidden, batch_first=True, bidirectional=True)
+    model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
+    return model.cuda().train()
+
+
+def _check_grads(model, want, tol_rel=1e-4, sampled=None):
+    for k, p_ in model.named_parameters():
+        assert p_.grad is not None, k
+        got = p_.grad.cpu().numpy()
+        if k.endswith("conv.bias"):
+            # A bias in front of a batch-statistics BatchNorm has gradient EXACTLY zero (the normalisation removes any constant);
+            # what either side holds is the rounding residue of sums over 1e5..1e6 terms, so only its smallness is comparable.
+            assert float(np.abs(got).max()) < 1e-3, (k, float(np.abs(got).max()))
+            continue
+        if sampled is not None and k in sampled:
+            idx_, val, absmax = sampled[k]
+            np.testing.assert_allclose(got.ravel()[idx_], val, rtol=0, atol=tol_rel * max(1.0, absmax), err_msg=k)
+        else:
+            w_ = want[k]
+            np.testing.assert_allclose(got, w_, rtol=0, atol=tol_rel * max(1.0, float(np.abs(w_).max())), err_msg=k)
+
+
+@pytest.mark.parametrize("idx", [0, 1])
+def test_train_step_reference_goldens(idx):
+    """G11 (the reference model's own train-mode step): the drop-in CTC_Model in train mode -- BatchNorm on batch statistics,
+    the reference's dropout masks handed in -- then the product CTCLoss(sum)/B and loss.backward(): log-probs within 1e-4,
+    loss, EVERY parameter gradient within 1e-4 of its scale, running statistics and num_batches_tracked updated as nn.BatchNorm does."""
+    from ctc_attention_mispronunciation_amd.train import CTCLoss
+    meta = jload("g11_train.json")[idx]
+    g = npz("g11_train.npz")
+    tag = meta["tag"]
+    geom = synth.Geometry(**meta["geom"])
+    sd, x, x1, masks, tg, il, tl = synth.train_case(geom, meta["seed"], meta["B"], meta["T"], meta["L"], meta["Lt"])
+    model = _train_model(geom, sd)
+    model._dropout_masks = [torch.from_numpy(m) for m in masks]
+    out = model(_cuda(x), _cuda(x1))
+    assert out.requires_grad and out.shape == g[tag + "_logp"].shape
+    np.testing.assert_allclose(out.detach().cpu().numpy(), g[tag + "_logp"], rtol=0, atol=TOL)
+    loss = CTCLoss(reduction="sum")(out, torch.from_numpy(tg), torch.from_numpy(il), torch.from_numpy(tl)) / meta["B"]    # train_ctc.py:72-74
+    assert abs(float(loss.detach()) - meta["loss"]) <= 1e-5 * abs(meta["loss"])
+    loss.backward()
+    full = {k[len(tag) + 6:]: g[k] for k in g.files if k.startswith(tag + "_grad_")}
+    sampled = {k[len(tag) + 6:]: (g[k], g[k.replace("_gidx_", "_gval_")], meta["tensors"][k[len(tag) + 6:]]["absmax"]) for k in g.files if k.startswith(tag + "_gidx_")}
+    _check_grads(model, full, sampled=sampled)
+    for k, info in meta["tensors"].items():
+        if k.endswith("conv.bias"):
+            continue                                        # exactly-zero gradients: rounding residue on both sides (see _check_grads)
+        gn = float(dict(model.named_parameters())[k].grad.double().norm())
+        assert abs(gn - info["norm"]) <= 1e-3 * max(info["norm"], 1e-2), (k, gn, info["norm"])
+    for k, b_ in model.named_buffers():
+        if "running_" in k:
+            np.testing.assert_allclose(b_.cpu().numpy(), g["%s_run_%s" % (tag, k)], rtol=0, atol=1e-5, err_msg=k)
+        elif k.endswith("num_batches_tracked"):
+            assert int(b_) == 8                             # synth writes 7
+
+
+@pytest.mark.parametrize("H,B,T,L", [(384, 3, 24, 6), (256, 5, 40, 9)])
+def test_train_step_against_torch_restatement(H, B, T, L):
+    """Shapes without a golden: every tensor in full against oracle/ref_port.train_step (torch autograd on ATen CPU ops, pinned
+    to the reference by G11) -- ragged lengths, batch sizes that are not tile multiples, H=384 and H=256."""
+    from oracle import ref_port
+    from ctc_attention_mispronunciation_amd.train import CTCLoss
+    geom = synth.Geometry(**dict(synth.REFERENCE, hidden=H))
+    sd, x, x1, masks, tg, il, tl = synth.train_case(geom, 100 + H, B, T, L, 4)
+    logp, loss, grads, run = ref_port.train_step(sd, x, x1, masks, tg, il, tl, 0.2)
+    model = _train_model(geom, sd)
+    model._dropout_masks = [torch.from_numpy(m) for m in masks]
+    out = model(_cuda(x), _cuda(x1))
+    np.testing.assert_allclose(out.detach().cpu().numpy(), logp, rtol=0, atol=TOL)
+    l2 = CTCLoss(reduction="sum")(out, torch.from_numpy(tg), torch.from_numpy(il), torch.from_numpy(tl)) / B
+    assert abs(float(l2) - loss) <= 1e-5 * abs(loss)
+    l2.backward()
+    _check_grads(model, grads)
+    for k, b_ in model.named_buffers():
+        if "running_" in k:
+            np.testing.assert_allclose(b_.cpu().numpy(), run[k], rtol=0, atol=1e-5, err_msg=k)
+
+
+def test_ctc_loss_module_matches_nn_ctcloss():
+    """The nn.CTCLoss-shaped callable (train_ctc.py:72,186): value and autograd gradient against the G5 goldens (torch's
+    CTCLoss(sum) + backward), then 'mean' / 'none', 1-D concatenated targets and zero_infinity against torch on the CPU."""
+    from ctc_attention_mispronunciation_amd.train import CTCLoss
+    g = npz("g5_ctc.npz")
+    for meta in jload("g5_ctc.json"):
+        i = meta["i"]
+        if not np.isfinite(g["nll%d" % i]).all():
+            continue
+        lp = _cuda(g["logp%d" % i]).requires_grad_(True)
+        loss = CTCLoss(reduction="sum")(lp, torch.from_numpy(g["tg%d" % i]), torch.from_numpy(g["il%d" % i]), torch.from_numpy(g["tl%d" % i]))
+        assert abs(float(loss) - meta["loss"]) <= 2e-6 * abs(meta["loss"]) + 1e-4
+        loss.backward()
+        np.testing.assert_allclose(lp.grad.cpu().numpy(), g["grad%d" % i], rtol=0, atol=TOL)
+    i = 7                                                    # the case with an infeasible row
+    lp_np, tg, il, tl = g["logp%d" % i], g["tg%d" % i], g["il%d" % i], g["tl%d" % i]
+    for red in ("mean", "none", "sum"):
+        for zi in (False, True):
+            ref = torch.nn.CTCLoss(reduction=red, zero_infinity=zi)(torch.from_numpy(lp_np), torch.from_numpy(tg), torch.from_numpy(il), torch.from_numpy(tl))
+            got = CTCLoss(reduction=red, zero_infinity=zi)(_cuda(lp_np), torch.from_numpy(tg), torch.from_numpy(il), torch.from_numpy(tl)).cpu()
+            np.testing.assert_allclose(got.numpy(), ref.numpy(), rtol=2e-6, atol=1e-4)
+    flat = torch.cat([torch.from_numpy(tg[b, :tl[b]]) for b in range(len(tl))])
+    a = CTCLoss(reduction="none")(_cuda(lp_np), flat, il.tolist(), tl.tolist()).cpu().numpy()
+    b = CTCLoss(reduction="none")(_cuda(lp_np), torch.from_numpy(tg), torch.from_numpy(il), torch.from_numpy(tl)).cpu().numpy()
+    np.testing.assert_array_equal(a, b)
+
+
+def test_adam_matches_torch_optim_adam():
+    """mdd_adam_step behind a torch.optim-compatible class against torch.optim.Adam (CPU) over several steps with the
+    reference's settings (lr 1e-3, weight_decay 5e-4; train_ctc.py:187), state_dict round trip included."""
+    from ctc_attention_mispronunciation_amd.train import Adam
+    rs = np.random.Generator(np.random.PCG64(1))
+    shapes = [(7,), (33, 5), (128, 129), (3, 4, 5, 6)]
+    p_ref = [torch.nn.Parameter(torch.from_numpy(rs.standard_normal(s).astype(np.float32))) for s in shapes]
+    p_hip = [torch.nn.Parameter(p.detach().clone().cuda()) for p in p_ref]
+    o_ref = torch.optim.Adam(p_ref, lr=1e-3, weight_decay=5e-4)
+    o_hip = Adam(p_hip, lr=1e-3, weight_decay=5e-4)
+    for step in range(6):
+        for a, b in zip(p_ref, p_hip):
+            gnp = (rs.standard_normal(a.shape) * (10.0 if step == 2 else 1.0)).astype(np.float32)
+            a.grad = torch.from_numpy(gnp); b.grad = torch.from_numpy(gnp).cuda()
+        o_ref.step(); o_hip.step()
+        if step == 3:                                        # halve the rate as the schedule does (train_ctc.py:215-268) and reload the state
+            for grp in o_ref.param_groups + o_hip.param_groups:
+                grp["lr"] *= 0.5
+            o_hip.load_state_dict(o_hip.state_dict())
+        for a, b in zip(p_ref, p_hip):
+            np.testing.assert_allclose(b.detach().cpu().numpy(), a.detach().numpy(), rtol=2e-6, atol=2e-7)
+    sd_ref, sd_hip = o_ref.state_dict(), o_hip.state_dict()
+    assert set(sd_ref["state"][0].keys()) <= set(sd_hip["state"][0].keys())
+
+
+def test_train_mode_generated_masks_and_full_loop():
+    """Without given masks the library draws them (counter-based generator): same seed -> same bits, keep-rate 1 - p; and a
+    short training loop of the drop-in pieces (model.train() forward, CTCLoss, backward, Adam) lowers the loss."""
+    from ctc_attention_mispronunciation_amd.train import CTCLoss, Adam
+    geom = synth.Geometry(**synth.REFERENCE_256)
+    sd, x, x1, _, tg, il, tl = synth.train_case(geom, 5, 4, 32, 6, 4)
+    model = _train_model(geom, sd)
+    xd, x1d = _cuda(x), _cuda(x1)
+    torch.manual_seed(3)
+    a = model(xd, x1d).detach().clone()
+    torch.manual_seed(3)
+    model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})     # undo the running-statistics update
+    b = model(xd, x1d).detach().clone()
+    assert torch.equal(a, b)
+    c = model(xd, x1d).detach()
+    assert not torch.equal(a, c)                              # the next draw differs
+    opt = Adam(model.parameters(), lr=1e-3, weight_decay=5e-4)
+    crit = CTCLoss(reduction="sum")
+    losses = []
+    for _ in range(8):
+        out = model(xd, x1d)
+        loss = crit(out, torch.from_numpy(tg), torch.from_numpy(il), torch.from_numpy(tl)) / 4
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        losses.append(float(loss))
+    assert losses[-1] < losses[0], losses
+    model.eval()
+    with torch.no_grad():
+        ev = model(xd, x1d)                                   # the eval path picks up the trained weights (its packed copies were stale)
+    assert torch.isfinite(ev).all() and float(torch.exp(ev.double()).sum(-1).sub(1).abs().max()) < 1e-5

@@ -225,3 +225,29 @@ def test_g9_benchmarked_length_and_chain(idx):
     check_chain(meta["records"], [ids_to_beam_string(s, i2c) for s in ids],
                 [ids_to_greedy_string(s, i2c) for s in oracle.greedy(logp, lens)], dec.wer,
                 lambda hyp, can: diagnose(hyp, can, dec))
+
+
+@pytest.mark.parametrize("idx", [0, 1])
+def test_g11_train_step_restatement(idx):
+    """G11: the reference model in train mode (batch-statistics BatchNorm, given dropout masks), CTCLoss(sum)/B, backward --
+    log-probs, loss, every parameter gradient, updated running statistics.  This pins oracle/ref_port.train_step (the torch
+    restatement that checks the HIP training step on shapes without a golden)."""
+    from oracle import ref_port
+    meta = jload("g11_train.json")[idx]
+    g = npz("g11_train.npz")
+    tag = meta["tag"]
+    geom = synth.Geometry(**meta["geom"])
+    sd, x, x1, masks, tg, il, tl = synth.train_case(geom, meta["seed"], meta["B"], meta["T"], meta["L"], meta["Lt"])
+    logp, loss, grads, run = ref_port.train_step(sd, x, x1, masks, tg, il, tl, 0.2)
+    np.testing.assert_allclose(logp, g[tag + "_logp"], rtol=0, atol=2e-6)
+    assert abs(loss - meta["loss"]) <= 1e-5 * abs(meta["loss"])
+    assert set(grads) == set(meta["tensors"])
+    for k, info in meta["tensors"].items():
+        tol = 2e-6 * max(1.0, info["absmax"])
+        if tag + "_grad_" + k in g.files:
+            np.testing.assert_allclose(grads[k], g[tag + "_grad_" + k], rtol=0, atol=tol, err_msg=k)
+        else:
+            np.testing.assert_allclose(grads[k].ravel()[g[tag + "_gidx_" + k]], g[tag + "_gval_" + k], rtol=0, atol=tol, err_msg=k)
+        assert abs(np.sqrt((grads[k].astype(np.float64) ** 2).sum()) - info["norm"]) <= 1e-4 * max(info["norm"], 1e-6), k
+    for k, v in run.items():
+        np.testing.assert_allclose(v, g["%s_run_%s" % (tag, k)], rtol=0, atol=1e-6, err_msg=k)
