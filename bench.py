@@ -46,7 +46,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=256)
     ap.add_argument("--warmup", type=int, default=32)
-    ap.add_argument("--workload", default="joint64", choices=["joint64", "greedy32", "ctc256"])
+    ap.add_argument("--workload", default="joint64", choices=["joint64", "greedy32", "ctc256", "train32"])
     ap.add_argument("--hidden", type=int, default=384)
     ap.add_argument("--fuse", type=int, default=8, help="reference-sized batches carried by one launch sequence")
     ap.add_argument("--ragged", action="store_true", help="headline on the ragged set (per-batch padding, unpadded frames counted)")
@@ -404,6 +404,72 @@ def ctc_workload(ctx, args):
                                     "note": "lattice recurrences are T' dependent steps per utterance: latency-, not bandwidth-bound at B=256"}
 
 
+def train_workload(ctx, args):
+    """BASELINE configs[4] per GPU: one training step of run_epoch (AA/steps/train_ctc.py:28-105) on a 32-utterance shard of the
+    global batch 256 = 8 x 32: train-mode forward (batch-statistics BatchNorm, dropout 0.2), CTCLoss(sum)/B, backward, gradient
+    all-reduce over the ranks (RCCL), Adam(lr 1e-3, weight_decay 5e-4).  fp32 arithmetic, as the reference trains (its config has no
+    attention-CE term and no bf16: SURVEY.md 8(a) A12)."""
+    import torch.nn as nn
+    from ctc_attention_mispronunciation_amd import synth
+    from ctc_attention_mispronunciation_amd.models.model_ctc import CTC_Model
+    from ctc_attention_mispronunciation_amd.steps.train_ctc import build_training, allreduce_gradients
+    B, T, L = 32, T_RAW // 2, L_CANON
+    geom = synth.Geometry(feat=3 * D_RAW, hidden=args.hidden, layers=4, num_class=N_CLASS)
+    sd = synth.synth_state_dict(geom, seed=1234)
+    model = CTC_Model(add_cnn=True, cnn_param=geom.cnn_param(nn), rnn_param=geom.rnn_param(nn), num_class=N_CLASS, drop_out=0.2)
+    model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
+    model = model.cuda().train()
+    model.strict_errors = False                                     # no host synchronisation inside the step
+    loss_fn, opt = build_training(model)
+    x, x1, frac, _ = synth.synth_batch(geom, B=B, T=T, L=L, seed=1234 + ctx.rank, ragged=False)
+    rs = np.random.Generator(np.random.PCG64(7 + ctx.rank))
+    xd, x1d = torch.from_numpy(x).cuda(), torch.from_numpy(x1).cuda()
+    tg = torch.from_numpy(rs.integers(2, 44, size=(B, L))).cuda()
+    il = torch.full((B,), T // 2, dtype=torch.int64).cuda()
+    tl = torch.full((B,), L, dtype=torch.int64).cuda()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
+    stage = np.zeros(4)
+
+    def step(timed):
+        if timed:
+            ev[0].record()
+        out = model(xd, x1d)
+        if timed:
+            ev[1].record()
+        loss = loss_fn(out, tg, il, tl) / B
+        opt.zero_grad()
+        loss.backward()
+        if timed:
+            ev[2].record()
+        allreduce_gradients(model)
+        if timed:
+            ev[3].record()
+        opt.step()
+        if timed:
+            ev[4].record()
+            torch.cuda.synchronize()
+            for k in range(4):
+                stage[k] += ev[k].elapsed_time(ev[k + 1])
+        return loss
+    for _ in range(max(args.warmup, 1)):
+        first = step(False)
+    ctx.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        last = step(False)
+    ctx.barrier()
+    dt = time.perf_counter() - t0
+    for _ in range(3):                                              # stage split, outside the timed region (it synchronises per step)
+        step(True)
+    if ctx.dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if ctx.dist.get_backend() == "gloo" else "cuda")
+        ctx.dist.all_reduce(t, op=ctx.dist.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt, B * (T // 2) * args.steps, {"forward_ms": round(stage[0] / 3, 3), "loss_backward_ms": round(stage[1] / 3, 3),
+                                              "allreduce_ms": round(stage[2] / 3, 3), "adam_ms": round(stage[3] / 3, 3),
+                                              "loss_first": round(float(first), 4), "loss_last": round(float(last), 4), "batch_per_gpu": B}
+
+
 def main():
     args = parse()
     from ctc_attention_mispronunciation_amd import _lib
@@ -419,6 +485,24 @@ def main():
                               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32 log-probs, f64 lattice",
                               "data": "synthetic", "config": {"workload": "CTC alpha/beta lattice loss+grad, B=256 x T'=250 x L=40, C=45"},
                               "roofline": roof, "cpu_baseline": None}))
+        return
+
+    if args.workload == "train32":
+        dt, frames, info = train_workload(ctx, args)
+        if rank == 0:
+            flop = 3.0 * 38.2e6 * (frames / args.steps)             # forward + ~2x for the backward, per step (38.2 MFLOP / frame)
+            print(json.dumps({"metric": "phoneme-frames/sec training step (fwd + CTC + bwd + all-reduce + Adam)", "value": round(world * frames / dt, 1),
+                              "unit": "phoneme-frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                              "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                              "dtype": "f32 (exact fp32 MFMA; the reference trains in fp32)", "data": "synthetic",
+                              "config": {"workload": "training step, B=32 per GPU x 10 s (global batch 32 x n_gpus; BASELINE configs[4] = 8 x 32), H=%d, L=40, dropout 0.2, "
+                                                     "Adam lr 1e-3 wd 5e-4" % args.hidden, **info},
+                              "roofline": {"kernel": "training step (all kernels)", "bound": "mfma", "achieved": round(flop / (dt / args.steps) / 1e12, 2),
+                                           "peak": PEAK_F32_MATRIX_TFLOPS, "unit": "TFLOP/s", "frac": round(flop / (dt / args.steps) / 1e12 / PEAK_F32_MATRIX_TFLOPS, 4),
+                                           "traffic": None, "note": "algorithmic flops of forward x3 over the whole step; the BiLSTM recurrences run as per-step launches"},
+                              "cpu_baseline": None}))
+        if ctx.dist is not None:
+            ctx.dist.destroy_process_group()
         return
 
     joint = args.workload == "joint64"

@@ -38,6 +38,15 @@ def main(rank, world_size, port):
     assert len(one) == 1 and one[0][0][:, 0].tolist() == [0, 1, 2] and one[0][1].tolist() == [1, 2, 3]
     tot = mdist.sum_counts([rank + 1, 10 * (rank + 1), 0, 0, 0, 0, 0, 7])
     assert tot == [sum(r + 1 for r in range(world_size)), 10 * sum(r + 1 for r in range(world_size)), 0, 0, 0, 0, 0, 7 * world_size]
+    # data-parallel gradient averaging of the training step (steps/train_ctc.py): buckets smaller than the model
+    from ctc_attention_mispronunciation_amd.steps.train_ctc import allreduce_gradients
+    net = torch.nn.Sequential(torch.nn.Linear(5, 7), torch.nn.Linear(7, 3))
+    for k, prm in enumerate(net.parameters()):
+        prm.grad = torch.full_like(prm, float((rank + 1) * (k + 1)))
+    allreduce_gradients(net, bucket_bytes=64)
+    mean_rank = sum(r + 1 for r in range(world_size)) / world_size
+    for k, prm in enumerate(net.parameters()):
+        assert torch.allclose(prm.grad, torch.full_like(prm, mean_rank * (k + 1))), (k, prm.grad)
     dist.barrier()
     dist.destroy_process_group()
     print("RESULT " + json.dumps(flat))

@@ -812,3 +812,29 @@ def test_train_mode_generated_masks_and_full_loop():
     with torch.no_grad():
         ev = model(xd, x1d)                                   # the eval path picks up the trained weights (its packed copies were stale)
     assert torch.isfinite(ev).all() and float(torch.exp(ev.double()).sum(-1).sub(1).abs().max()) < 1e-5
+
+
+def test_run_epoch_mirror_trains_and_validates():
+    """steps/train_ctc.run_epoch (the reference's loop, train_ctc.py:28-105) over an in-memory loader of create_input batches:
+    a training epoch then a validation epoch; returns (accuracy, mean loss), parameters move only in training."""
+    from ctc_attention_mispronunciation_amd.steps.train_ctc import run_epoch, build_training
+    from ctc_attention_mispronunciation_amd.utils.data_loader import create_input
+    geom = synth.Geometry(**synth.REFERENCE_256)
+    sd = synth.synth_state_dict(geom, seed=9)
+    model = _train_model(geom, sd)
+    rs = np.random.Generator(np.random.PCG64(4))
+    batches = []
+    for k in range(3):
+        items = []
+        for u in range(4):
+            T = int(rs.integers(10, 17)) * 2
+            items.append((torch.from_numpy(rs.standard_normal((T, 243)).astype(np.float32)), torch.from_numpy(rs.integers(2, 44, size=int(rs.integers(2, 5)))),
+                          torch.from_numpy(rs.integers(2, 44, size=int(rs.integers(3, 8)))), "u%d_%d" % (k, u)))
+        batches.append(create_input(items))
+    loss_fn, opt = build_training(model)
+    w0 = model.fc[1].weight.detach().clone()
+    acc, loss = run_epoch(1, model, batches, loss_fn, "cuda", optimizer=opt, print_every=2, is_training=True)
+    assert np.isfinite(loss) and acc <= 1.0 and not torch.equal(w0, model.fc[1].weight)
+    w1 = model.fc[1].weight.detach().clone()
+    acc2, loss2 = run_epoch(1, model, batches, loss_fn, "cuda", optimizer=None, is_training=False)
+    assert np.isfinite(loss2) and torch.equal(w1, model.fc[1].weight) and not model.training

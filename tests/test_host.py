@@ -194,3 +194,39 @@ def test_speech_dataset_reads_ark_and_collates(tmp_path):
     random.seed(3); np.random.seed(3)
     f2, _ = tools.augment_item(feats["u2"], [2, 4], train=True)
     np.testing.assert_array_equal(xa.numpy()[:9], tools.skip_feat(tools.make_context(f2, 0, 2), 2))
+
+
+def test_lr_schedule_state_machine():
+    """The dev-loss driven halving of train_ctc.py:207-268 (inline code in the reference's main(); restated, no function to call):
+    patience of ten epochs inside the band, immediate decay outside it, best state restored, stop after eight adjustments."""
+    import torch
+    from ctc_attention_mispronunciation_amd.steps.train_ctc import LrSchedule
+    net = torch.nn.Linear(2, 2)
+    opt = torch.optim.SGD(net.parameters(), lr=1.0)
+    s = LrSchedule(net, opt, init_lr=1.0, decay=0.5, end_adjust_acc=2.0, num_epoches=100)
+    assert s.begin_epoch()
+    s.end_epoch(0.5, 50.0)                      # first epoch: new best
+    assert s.loss_best == 50.0 and s.adjust_rate_count == 0
+    with torch.no_grad():
+        net.weight.fill_(7.0)
+    assert s.begin_epoch()
+    s.end_epoch(0.4, 60.0)                      # far worse than best + band: decay at once, best weights restored
+    assert s.adjust_time == 1 and s.adjust_rate_flag and float(net.weight[0, 0]) != 7.0
+    assert s.begin_epoch() and opt.param_groups[0]["lr"] == 0.5 and s.learning_rate == 0.5
+    for k in range(9):                          # inside the band: patience counts up
+        s.end_epoch(0.4, 49.5)
+        assert s.adjust_time == 1 and s.adjust_rate_count == k + 1, k
+        assert s.begin_epoch()
+    assert s.loss_best == 50.0 and s.loss_best_true == 49.5
+    s.end_epoch(0.4, 49.0)                      # tenth epoch inside the band: decay, loss_best follows the true best
+    assert s.adjust_time == 2 and s.loss_best == 49.0
+    epochs = 0
+    while s.begin_epoch():
+        s.end_epoch(0.1, 99.0)
+        epochs += 1
+    assert s.adjust_time == 8 and s.stop_train and epochs == 6 and abs(s.learning_rate - 0.5 ** 7) < 1e-12
+    # reference quirk kept: optimizer.load_state_dict(op_state) also restores the RATE stored with the best state, so the optimizer's
+    # own lr is (rate at the best epoch) x decay, not the printed `learning_rate` (train_ctc.py:219-224, 262)
+    assert opt.param_groups[0]["lr"] == 0.5
+    assert s.acc_best == 0.5
+    s.finish()
