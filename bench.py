@@ -9,11 +9,13 @@ Workload (BASELINE.json configs[2], the configuration the metric is quoted on): 
 canonical length 40, beam 10, lm_alpha 0.  `--workload greedy32` runs configs[1] (B=32, greedy decode),
 `--workload ctc256` the CTC alpha/beta lattice (loss + gradient) of configs[4]'s global batch.
 
-The headline `value` fuses `--fuse` (default 8) same-shape batches into one launch sequence, which the
-reference's no-mask semantics allow only for batches of identical T and Lmax.  What real (ragged) data gets is
-reported in the same JSON line under `variants` (same run, rank 0, N=1): `fuse1` (a lone B=64 batch per pass),
-`ragged` (len ~ U[0.5,1] x 10 s, every batch padded to its own maximum, frames counted unpadded), `f32_mode`
-(exact-fp32 MFMA arithmetic, MDD_PRECISION=f32) and `greedy32_h256` (configs[1]).
+The headline `value` carries `--fuse` (default 8) reference batches per launch sequence (every utterance full length).  The
+reference masks nothing, so an utterance's result depends on its batch's padded lengths; mdd_forward_fused carries batches of
+DIFFERENT padded lengths in one launch sequence with per-row (T_g, L_g), bit-identical to running each batch alone.  What real
+(ragged) data gets is reported in the same JSON line under `variants` (same run, rank 0, N=1): `ragged` (len ~ U[0.5,1] x 10 s,
+every batch padded to its own maximum, 8 such batches per fused pass, frames counted UNPADDED), `ragged_fuse1` / `fuse1` (a lone
+B=64 batch per pass: the latency-bound case), `f32_mode` (exact-fp32 MFMA arithmetic, MDD_PRECISION=f32) and `greedy32_h256`
+(configs[1]).
 
 N>1 (launched by torch.distributed.run, one rank per GPU): utterance batches shard across ranks (weak
 scaling: every rank decodes its own 64-utterance batch) and the posteriors of all shards are all-gathered
@@ -134,8 +136,8 @@ class DecodeJob(object):
             # frame replicated at ITS edge, data_loader.py:138-142), each batch zero-padded to its own maximum (:159,173)
             # and run alone (a fused pass needs identical T and Lmax).  Canonical lengths ~ U[0.5,1] x 40, padded per batch.
             rs = np.random.Generator(np.random.PCG64(seed))
-            self.rag = []
-            for k in range(8):
+            batches = []
+            for k in range(8 if fuse == 1 else 2 * fuse):
                 lens_raw = rs.integers(T_RAW // 2, T_RAW + 1, size=self.B0)
                 raw = synth.synth_raw_features(self.B0, T_RAW, D_RAW, seed=seed + 100 * (k + 1))
                 t_st = [int((n + 1) // 2 + ((n + 1) // 2) % 2) for n in lens_raw]        # mdd_stack_len(n, 2, 2)
@@ -150,8 +152,23 @@ class DecodeJob(object):
                     x1[b, :llen[b]] = rs.integers(2, 44, size=llen[b])
                 frac = torch.tensor([t / T for t in t_st]).float()                          # data_loader.py:177
                 lens = (frac * (T // 2)).long().to(torch.int32)                             # infer.py:296-297
-                self.rag.append(dict(x=x, x1=torch.from_numpy(x1).cuda(), x1_np=x1, lens=lens.cuda(), T=T, canon_len=llen.astype(np.int32),
-                                     frames=int(lens.sum())))
+                batches.append(dict(x=x, x1_np=x1, lens=lens, T=T, L=Lm, canon_len=llen.astype(np.int32)))
+            # a pass = `fuse` of those batches in one launch sequence (mdd_forward_fused): common T / L, per-row (T_g/2, L_g)
+            self.rag = []
+            for k0 in range(0, len(batches), fuse):
+                grp = batches[k0:k0 + fuse]
+                Tm, Lm, nb = max(g["T"] for g in grp), max(g["L"] for g in grp), self.B0 * len(grp)
+                X = torch.zeros((nb, Tm, 3 * D_RAW), device="cuda")
+                X1 = np.zeros((nb, Lm), dtype=np.int64)
+                frames, canon = np.zeros(nb, dtype=np.int32), np.zeros(nb, dtype=np.int32)
+                for i, g in enumerate(grp):
+                    r = slice(i * self.B0, (i + 1) * self.B0)
+                    X[r, :g["T"]] = g["x"]; X1[r, :g["L"]] = g["x1_np"]; frames[r] = g["T"] // 2; canon[r] = g["L"]
+                self.rag.append(dict(x=X, x1=torch.from_numpy(X1).cuda(), x1_np=X1, lens=torch.cat([g["lens"] for g in grp]).cuda(), T=Tm,
+                                     canon_len=np.concatenate([g["canon_len"] for g in grp]), frames=int(sum(int(g["lens"].sum()) for g in grp)),
+                                     padded=int(sum(g["T"] // 2 * self.B0 for g in grp)), nb=nb, batches=len(grp),
+                                     bframes=torch.from_numpy(frames).cuda(), bcanon=torch.from_numpy(canon).cuda()))
+            del batches
         torch.cuda.synchronize()
 
     class Bufs(object):
@@ -185,8 +202,8 @@ class DecodeJob(object):
         r = self.rag[k]
         if "bf" not in r:
             bf = DecodeJob.Bufs()
-            bf.b, bf.Tp = self.B0, r["T"] // 2
-            bf.x, bf.x1, bf.lens = r["x"], r["x1"], r["lens"]
+            bf.b, bf.Tp = r["nb"], r["T"] // 2
+            bf.x, bf.x1, bf.lens, bf.bframes, bf.bcanon = r["x"], r["x1"], r["lens"], r["bframes"], r["bcanon"]
             bf.canon = np.ascontiguousarray(r["x1_np"], dtype=np.int32)
             bf.canon_len = r["canon_len"]
             bf.frames = r["frames"]
@@ -202,7 +219,10 @@ class DecodeJob(object):
         with torch.cuda.stream(self.s_fwd):
             self.s_fwd.wait_event(self.ev_free[k])          # slot k's buffers no longer read by the decoder two passes ago
             if self.ragged:
-                self.model.forward(bf.x, bf.x1, out=bf.logp[k])
+                if self.fuse > 1:
+                    self.model.forward_fused(bf.x, bf.x1, bf.bframes, bf.bcanon, out=bf.logp[k])
+                else:
+                    self.model.forward(bf.x, bf.x1, out=bf.logp[k])
             else:
                 self.model.forward_raw(bf.raw, bf.x1, out=bf.logp[k])    # stack/skip folded into the front-end's tile load
             if bf.gathered is not None:
@@ -230,8 +250,8 @@ class DecodeJob(object):
         self.frames_done += bf.frames
 
     def items(self, nsteps):
-        if self.ragged:
-            return [i % len(self.rag) for i in range(nsteps)]
+        if self.ragged:          # a step is one reference batch; a pass carries `fuse` of them
+            return [i % len(self.rag) for i in range((nsteps + self.fuse - 1) // self.fuse)]
         G = max(1, min(self.fuse, nsteps))
         return [G] * (nsteps // G) + ([nsteps % G] if nsteps % G else [])
 
@@ -363,10 +383,10 @@ def variant(ctx, args, name, **kw):
     job = DecodeJob(ctx, args, **kw)
     dt, frames = job.timed(steps, warmup)
     out = {"value": round(frames / dt, 1), "unit": "phoneme-frames/s", "ms_per_step": round(dt / steps * 1e3, 4), "steps": steps,
-           "batch": job.B0, "batches_fused_per_pass": 1 if job.ragged else max(1, min(job.fuse, steps)), "hidden": kw["hidden"],
+           "batch": job.B0, "batches_fused_per_pass": max(1, min(job.fuse, steps)), "hidden": kw["hidden"],
            "decoder": job.decoder_kind, "precision": job.model.precision}
     if job.ragged:
-        out["padded_frames_per_s"] = round(sum(r["T"] // 2 * job.B0 for r in job.rag) / len(job.rag) * steps / dt, 1)
+        out["padded_frames_per_s"] = round(frames / dt * sum(r["padded"] for r in job.rag) / sum(r["frames"] for r in job.rag), 1)
     if want_roof and not args.no_roofline:
         r = job.roofline(max(1, min(job.fuse, steps)))
         out["roofline"] = {k: r[k] for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "avg_launch_us", "kernel_classes_ms")}
@@ -509,7 +529,7 @@ def main():
     job = DecodeJob(ctx, args, hidden=args.hidden, joint=joint, fuse=args.fuse, ragged=args.ragged, precision=args.precision,
                     decoder_kind=args.decoder, gather=not args.no_gather)
     dt, frames = job.timed(args.steps, args.warmup)
-    G = 1 if args.ragged else max(1, min(args.fuse, args.steps))
+    G = max(1, min(args.fuse, args.steps))
     if ctx.dist is not None:
         ft = torch.tensor([frames], dtype=torch.float64, device="cpu" if ctx.dist.get_backend() == "gloo" else "cuda")
         ctx.dist.all_reduce(ft)
@@ -553,7 +573,8 @@ def main():
     if rank == 0 and world == 1 and not args.no_variants and joint and not args.ragged:
         variants = {
             "fuse1": variant(ctx, args, "fuse1", hidden=args.hidden, joint=True, fuse=1, ragged=False, precision=args.precision, steps=32, warmup=8),
-            "ragged": variant(ctx, args, "ragged", hidden=args.hidden, joint=True, fuse=1, ragged=True, precision=args.precision, steps=32, warmup=8),
+            "ragged": variant(ctx, args, "ragged", hidden=args.hidden, joint=True, fuse=args.fuse, ragged=True, precision=args.precision, steps=64, warmup=16),
+            "ragged_fuse1": variant(ctx, args, "ragged_fuse1", hidden=args.hidden, joint=True, fuse=1, ragged=True, precision=args.precision, steps=32, warmup=8),
             "f32_mode": variant(ctx, args, "f32_mode", hidden=args.hidden, joint=True, fuse=args.fuse, ragged=False, precision="f32", steps=16, warmup=8,
                                 roofline=True),
             "greedy32_h256": variant(ctx, args, "greedy32_h256", hidden=256, joint=False, fuse=args.fuse, ragged=False, precision=args.precision,
@@ -575,7 +596,7 @@ def main():
                                     if joint else "CTC-only greedy decode: stack/skip + forward + greedy + align, B=32 x 10 s"),
                        "batch_per_gpu": B0, "global_batch": B0 * world, "batches_fused_per_pass": G,
                        "lengths": "ragged: len ~ U[0.5,1] x 10 s, per-batch padding, unpadded frames counted" if args.ragged else
-                                  "all utterances full length (fusing batches requires identical T and Lmax: see variants.fuse1 / variants.ragged)",
+                                  "all utterances full length (ragged batches, fused with per-row lengths: variants.ragged; a lone batch per pass: variants.fuse1)",
                        "t_raw": T_RAW, "posterior_frames": T_RAW // 4,
                        "hidden": args.hidden, "layers": 4, "num_class": N_CLASS, "canonical_len": L_CANON,
                        "decoder": decoder_kind, "beam": BEAM_W if decoder_kind == "beam" else 0, "lm_alpha": 0.0,

@@ -14,7 +14,7 @@ MDD_ERR_EMPTY = -5   # include/mdd_hip.h: an empty sequence where the reference 
 
 EXPORTS = (
     "mdd_last_error", "mdd_version", "mdd_create", "mdd_destroy", "mdd_load_weight", "mdd_finalize_weights",
-    "mdd_set_precision", "mdd_get_precision", "mdd_stack_len", "mdd_stack_skip", "mdd_len_frames", "mdd_forward", "mdd_forward_raw", "mdd_forward_num_stages", "mdd_forward_profile", "mdd_tap", "mdd_tap_copy", "mdd_enable_taps", "mdd_sync",
+    "mdd_set_precision", "mdd_get_precision", "mdd_stack_len", "mdd_stack_skip", "mdd_len_frames", "mdd_forward", "mdd_forward_fused", "mdd_forward_raw", "mdd_forward_num_stages", "mdd_forward_profile", "mdd_tap", "mdd_tap_copy", "mdd_enable_taps", "mdd_sync",
     "mdd_greedy", "mdd_beam", "mdd_ctc_loss", "mdd_ctc_workspace_bytes", "mdd_align", "mdd_align_batch", "mdd_eval_batch", "mdd_fbank_num_frames", "mdd_fbank",
     "mdd_train_create", "mdd_train_destroy", "mdd_train_num_tensors", "mdd_train_tensor_info", "mdd_train_num_masks", "mdd_train_mask_bytes",
     "mdd_train_forward", "mdd_train_backward", "mdd_train_sync", "mdd_adam_step",
@@ -62,6 +62,7 @@ def lib():
     L.mdd_len_frames.restype = i32
     L.mdd_forward.argtypes = [vp, vp, i32, i32, vp, i32, vp, vp]
     L.mdd_forward_raw.argtypes = [vp, vp, i32, i32, vp, i32, vp, vp]
+    L.mdd_forward_fused.argtypes = [vp, vp, i32, i32, vp, i32, vp, vp, vp, vp]
     L.mdd_forward_num_stages.argtypes = [vp]
     L.mdd_forward_profile.argtypes = [vp, vp, i32, i32, vp, i32, vp, vp, C.c_char_p, i32, vp, vp, vp, i32]
     L.mdd_tap.argtypes = [vp, C.c_char_p, i64p]

@@ -41,7 +41,7 @@ struct DevBuf {
 };
 
 struct GraphKey {
-    const void *x, *x1, *out;
+    const void *x, *x1, *out, *tlen, *llen;
     int B, T, L, Traw;
     bool operator<(const GraphKey &o) const { return memcmp(this, &o, sizeof(GraphKey)) < 0; }
 };
@@ -72,6 +72,7 @@ struct mdd_model {
     hipStream_t cap_stream = nullptr;  // graphs are captured here (the legacy default stream cannot capture)
     int lastB = 0, lastT = 0, lastL = 0;
     int raw_T = 0;              // > 0 while mdd_forward_raw runs the fused front-end straight on unstacked frames
+    const int *tlen = nullptr, *llen = nullptr;   // set while mdd_forward_fused runs: per-row posterior frames / canonical length of the row's own batch
     mdd::DevBuf xstack;         // mdd_forward_raw without the fused front-end: stacked copy
     std::map<mdd::GraphKey, hipGraphExec_t> graphs;
     int W1() const { return (cfg.feat + 2 - 3) / 2 + 1; }
@@ -246,6 +247,7 @@ static int run_stage(mdd_model *m, int si, const float *x, int B, int T, const i
         a.gx = m->gx.p; a.whh = m->whh[n]; a.hbuf = m->hbuf.p; a.cbuf = m->cbuf.p;
         a.T = Tp; a.B = B; a.H = H; a.packed = use_packed(m);
         a.whh_split = m->whh_s[n]; a.hsplit = (x3 && m->lstm_x3) ? reinterpret_cast<unsigned short *>(m->hsplit.p) : nullptr;
+        a.seqlen = m->tlen;
         if (n == nl - 1) {   // raw h: the attention queries X (fp32 for the tail, split for the score GEMM)
             a.out = m->xraw.p; a.out_raw = m->xraw.p; a.oscale = nullptr; a.oshift = nullptr;
             a.out_split = x3 ? split_view(m->x_s, rows * H2) : kNoSplit;
@@ -276,6 +278,7 @@ static int run_stage(mdd_model *m, int si, const float *x, int B, int T, const i
         a.out_split = x3 ? split_view(m->text_s, trows * H2) : kNoSplit;
         a.T = L; a.B = B; a.H = H; a.packed = use_packed(m);
         a.whh_split = m->t_whh_s; a.hsplit = (x3 && m->lstm_x3) ? reinterpret_cast<unsigned short *>(m->hsplit.p) : nullptr;
+        a.seqlen = m->llen;
         if (m->persist(B)) { info->launches = 1; return ((m->lstm_granule && B <= m->granule_max_b) ? launch_lstm_layer_granule : launch_lstm_layer_persistent)(a, reinterpret_cast<unsigned short *>(m->hx.p), m->sync_words, m->err_flag, st); }
         return launch_lstm_layer(a, st);
     }
@@ -294,7 +297,7 @@ static int run_stage(mdd_model *m, int si, const float *x, int B, int T, const i
         return launch_gemm_nt(m->xraw.p, m->key.p, nullptr, m->S.p, Tp, L, H2, B * H2, B * H2, Lp, B, H2, H2, (long)Tp * Lp, st);
     default:
         info->name = "attn_tail"; info->flops = 2.0 * (double)B * Tp * ((double)L * H2 + 2.0 * H2 * c.num_class);
-        return launch_attn_tail(m->S.p, Lp, m->xraw.p, m->text.p, m->fscale, m->fshift, m->w_fc, m->w_fcp, logp, Tp, B, L, H2, c.num_class, st);
+        return launch_attn_tail(m->S.p, Lp, m->xraw.p, m->text.p, m->fscale, m->fshift, m->w_fc, m->w_fcp, logp, Tp, B, L, H2, c.num_class, st, m->llen);
     }
 }
 
@@ -596,7 +599,7 @@ extern "C" int mdd_forward(mdd_model *m, const float *x_dev, int32_t B, int32_t 
     }
     GraphKey key;
     memset(&key, 0, sizeof(key));
-    key.x = x_dev; key.x1 = x1_dev; key.out = logp_dev; key.B = B; key.T = T; key.L = L; key.Traw = m->raw_T;
+    key.x = x_dev; key.x1 = x1_dev; key.out = logp_dev; key.B = B; key.T = T; key.L = L; key.Traw = m->raw_T; key.tlen = m->tlen; key.llen = m->llen;
     auto it = m->graphs.find(key);
     if (it == m->graphs.end()) {
         if (m->graphs.size() >= 8) { for (auto &kv : m->graphs) (void)hipGraphExecDestroy(kv.second); m->graphs.clear(); }
@@ -617,6 +620,25 @@ extern "C" int mdd_forward(mdd_model *m, const float *x_dev, int32_t B, int32_t 
     hipError_t le = hipGraphLaunch(it->second, st);
     if (le != hipSuccess) { set_error("hipGraphLaunch failed: %s", hipGetErrorString(le)); return gate_leave(m, st, held, MDD_ERR_HIP); }
     return gate_leave(m, st, held, MDD_OK);
+}
+
+// Several reference batches of DIFFERENT padded lengths in one launch sequence.  The reference pads every batch to its own
+// maximum and masks nothing (AA/models/model_ctc.py:186,198,204-205), so an utterance's posteriors depend on its batch's
+// padded length T_g and canonical length L_g: rows of batch g carry frames_dev[b] = T_g / 2 and canon_dev[b] = L_g.  What
+// depends on the batch's length -- where the reverse BiLSTM direction starts (frame T_g/2 - 1 / token L_g - 1, zero state) and
+// which keys the attention softmax runs over (l < L_g) -- follows those per-row values; everything else is row-local.  x_dev
+// [B, T, F] is zero beyond each batch's T_g (as the collate's zero padding leaves it), x1_dev [B, L] is zero-padded.  Rows
+// t >= frames_dev[b] of logp_dev are not meaningful.  Results for every utterance are bit-identical to running its batch alone.
+extern "C" int mdd_forward_fused(mdd_model *m, const float *x_dev, int32_t B, int32_t T, const int64_t *x1_dev, int32_t L,
+                                 const int32_t *frames_dev, const int32_t *canon_dev, float *logp_dev, void *stream) {
+    if (!m || !frames_dev || !canon_dev) { set_error("mdd_forward_fused: null pointer"); return MDD_ERR_ARG; }
+    if (m->finalized && m->persist(B) && !(m->lstm_granule && B <= m->granule_max_b)) {
+        set_error("mdd_forward_fused: needs the granule form of the persistent BiLSTM or the step kernels (MDD_LSTM=counter is not supported)"); return MDD_ERR_ARG;
+    }
+    m->tlen = frames_dev; m->llen = canon_dev;
+    const int rc = mdd_forward(m, x_dev, B, T, x1_dev, L, logp_dev, stream);
+    m->tlen = nullptr; m->llen = nullptr;
+    return rc;
 }
 
 // A1 + forward in one call: raw_dev = unstacked frames [B, T_raw, feat/3].  With the fused conv front-end the stack/skip

@@ -46,10 +46,12 @@ constexpr int TT = 16;  // posterior frames per workgroup
 __global__ __launch_bounds__(256) void attn_tail_kernel(const float *__restrict__ S, int Lp, const float *__restrict__ X,
                                                         const float *__restrict__ V, const float *__restrict__ fscale,
                                                         const float *__restrict__ fshift, const float *__restrict__ wfc,
-                                                        float *__restrict__ logp, int Tp, int B, int L, int H2, int C) {
+                                                        float *__restrict__ logp, int Tp, int B, int Lmax, int H2, int C,
+                                                        const int *__restrict__ llen) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int L = llen ? min(max(llen[blockIdx.y], 1), Lmax) : Lmax;   // this utterance's own batch's canonical length (fused batches)
     float *attw = smem;                 // [TT][L]
-    float *y = attw + TT * L;           // [TT][2*H2]
+    float *y = attw + TT * Lmax;        // [TT][2*H2]
     float *lg = y + TT * 2 * H2;        // [TT][C]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.y, t0 = blockIdx.x * TT;
@@ -136,11 +138,15 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(256, 2) void attn_tail_mfma_kernel(const float *__restrict__ S, int Lp, const float *__restrict__ X,
                                                              const float *__restrict__ V, const float *__restrict__ fscale,
                                                              const float *__restrict__ fshift, const float *__restrict__ wfcp,
-                                                             float *__restrict__ logp, int Tp, int B, int L, int H2, int C) {
+                                                             float *__restrict__ logp, int Tp, int B, int Lmax, int H2, int C,
+                                                             const int *__restrict__ llen) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    // fused batches of different canonical lengths: this utterance attends over the l < llen[b] of its own batch (the same
+    // arithmetic, in the same order, as a launch with L = llen[b]); the LDS tile is sized for Lmax
+    const int L = llen ? min(max(llen[blockIdx.y], 1), Lmax) : Lmax;
     const int D2 = 2 * H2, LDY = H2 + 4, LA = (L + 3) & ~3;
     float *attw = smem;                  // [16][LA]
-    float *yc = attw + 16 * LA;          // [16][LDY]   context half of y
+    float *yc = attw + 16 * ((Lmax + 3) & ~3);   // [16][LDY]   context half of y
     float *part = yc + 16 * LDY;         // [4][16][48]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, kq = lane >> 4;
@@ -306,13 +312,13 @@ __global__ __launch_bounds__(256, 2) void attn_tail_mfma_kernel(const float *__r
 }
 
 int launch_attn_tail(const float *S, int Lp, const float *X, const float *V, const float *fscale, const float *fshift,
-                     const float *wfc, const float *wfcp, float *logp, int Tp, int B, int L, int H2, int C, hipStream_t st) {
+                     const float *wfc, const float *wfcp, float *logp, int Tp, int B, int L, int H2, int C, hipStream_t st, const int *llen) {
     if (wfcp && (2 * H2) % 256 == 0 && C <= 48) {
         const int D2 = 2 * H2, LA = (L + 3) & ~3;
         size_t smem = sizeof(float) * ((size_t)16 * LA + (size_t)16 * (H2 + 4) + 4 * 16 * 48);
         if (smem > 160 * 1024) { set_error("attn_tail: L=%d too long for the LDS tile (%zu B)", L, smem); return MDD_ERR_ARG; }
         hipLaunchKernelGGL(attn_tail_mfma_kernel, dim3((Tp + 15) / 16, B), dim3(256), smem, st, S, Lp, X, V, fscale, fshift, wfcp,
-                           logp, Tp, B, L, H2, C);
+                           logp, Tp, B, L, H2, C, llen);
         MDD_LAUNCH_CHECK();
         return MDD_OK;
     }
@@ -321,7 +327,7 @@ int launch_attn_tail(const float *S, int Lp, const float *X, const float *V, con
     if (smem > 160 * 1024) { set_error("attn_tail: L=%d too long for the LDS tile (%zu B)", L, smem); return MDD_ERR_ARG; }
     // y starts 16-byte aligned because TT*L*4 % 16 == 0 for TT = 16.
     dim3 grid((Tp + TT - 1) / TT, B), block(256);
-    hipLaunchKernelGGL(attn_tail_kernel, grid, block, smem, st, S, Lp, X, V, fscale, fshift, wfc, logp, Tp, B, L, H2, C);
+    hipLaunchKernelGGL(attn_tail_kernel, grid, block, smem, st, S, Lp, X, V, fscale, fshift, wfc, logp, Tp, B, L, H2, C, llen);
     MDD_LAUNCH_CHECK();
     return MDD_OK;
 }

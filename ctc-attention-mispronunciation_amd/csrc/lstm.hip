@@ -68,8 +68,9 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(LstmStepArgs a, int s) {
         const float cold = s > 0 ? a.cbuf[ci] : 0.f;
         const float ig = sigmoid_f(acc[0] + g4.x), fg = sigmoid_f(acc[1] + g4.y);
         const float gg = tanhf(acc[2] + g4.z), og = sigmoid_f(acc[3] + g4.w);
-        const float cn = fg * cold + ig * gg;
-        const float hn = og * tanhf(cn);
+        const bool hold = d && a.seqlen && t >= a.seqlen[b];     // reverse direction has not reached this row's last step yet
+        const float cn = hold ? 0.f : fg * cold + ig * gg;
+        const float hn = hold ? 0.f : og * tanhf(cn);
         a.cbuf[ci] = cn;
         hnext[(size_t)b * H + u] = hn;
         if (a.gates_save) {   // train mode: what the backward sweep needs (train_kernels.hip)
@@ -141,8 +142,9 @@ __global__ __launch_bounds__(256, 1) void lstm_step_packed_kernel(LstmStepArgs a
         const float gg = (acc0[2] + acc1[2]) + (acc2[2] + acc3[2]) + g4.z;
         const float go = (acc0[3] + acc1[3]) + (acc2[3] + acc3[3]) + g4.w;
         const float ig = sigmoid_f(gi), fg = sigmoid_f(gf), cg = tanhf(gg), og = sigmoid_f(go);
-        const float cn = fg * cold + ig * cg;
-        const float hn = og * tanhf(cn);
+        const bool hold = d && a.seqlen && t >= a.seqlen[b];
+        const float cn = hold ? 0.f : fg * cold + ig * cg;
+        const float hn = hold ? 0.f : og * tanhf(cn);
         a.cbuf[ci] = cn;
         float *hnext = a.hbuf + (s & 1) * hplane;
         hnext[(((size_t)(d * NBT + bt) * J + (ut >> 2)) * 64 + (ut & 3) * 16 + li) * 4 + uu] = hn;
@@ -263,8 +265,9 @@ __global__ __launch_bounds__(256, 1) void lstm_step_x3_kernel(LstmStepArgs a, in
         const float cold = s > 0 ? a.cbuf[ci] : 0.f;
         const float ig = fast_sigmoid(acc[rt][0] + g4.x), fg = fast_sigmoid(acc[rt][1] + g4.y);
         const float cg = fast_tanh(acc[rt][2] + g4.z), og = fast_sigmoid(acc[rt][3] + g4.w);
-        const float cn = fg * cold + ig * cg;
-        const float hn = og * fast_tanh(cn);
+        const bool hold = d && a.seqlen && t >= a.seqlen[b];
+        const float cn = hold ? 0.f : fg * cold + ig * cg;
+        const float hn = hold ? 0.f : og * fast_tanh(cn);
         a.cbuf[ci] = cn;
         {
             const unsigned int pk = split_h(hn);
@@ -325,6 +328,7 @@ struct PersistArgs {
     const float *oscale, *oshift;
     int T, B, BG, BGr;               // BG: padded rows per group (multiple of 16), BGr: real rows per group
     long long *dbg;                  // diagnostic builds only: per-workgroup cycle sums of the step phases (null in production)
+    const int *seqlen;               // see LstmStepArgs::seqlen (null = every row runs all T steps)
     int early;                       // diagnostic (MDD_LSTM_EARLY): request the next tile's panel a whole MFMA section too early, so that stale panels and the redo path occur
 };
 
@@ -611,6 +615,12 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_granule_kernel(PersistArgs 
     for (int rt = 0; rt < RTW; rt++)
 #pragma unroll
         for (int bt = 0; bt < NBT; bt++) cst[rt][bt] = 0.f;
+    int slen[NBT];                                                  // steps valid for this lane's batch row of tile bt (fused batches of different lengths)
+#pragma unroll
+    for (int bt = 0; bt < NBT; bt++) {
+        const int lb = bt * 16 + li, row = g * a.BGr + lb;
+        slen[bt] = (a.seqlen && lb < a.BGr && row < B) ? a.seqlen[row] : T;
+    }
     // A tile panel in the exchange buffer and in LDS: 16-byte chunks {4 tagged words = 4 consecutive units of one row},
     // chunk index = (unit / 4) * 16 + row.  A workgroup's share (its UW units x 16 rows) is then ONE contiguous run, the
     // sweep is a linear copy, and the MFMA operand of lane (row li, k-quarter kq) at k-step ks is the two chunks
@@ -854,10 +864,11 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_granule_kernel(PersistArgs 
             for (int rt = 0; rt < RTW; rt++) {   // branch-free: the row tiles' chains interleave
                 const float ig = fast_sigmoid(acc[rt][0] + gv[rt].x), fg = fast_sigmoid(acc[rt][1] + gv[rt].y);
                 const float cg = fast_tanh(acc[rt][2] + gv[rt].z), og = fast_sigmoid(acc[rt][3] + gv[rt].w);
+                const bool live = !(d && t >= slen[bt]);              // the reverse direction starts at the row's own last step, from a zero state
                 const float cn = fg * cst[rt][bt] + ig * cg;
                 const float hr = og * fast_tanh(cn);
-                hn[rt] = valid ? hr : 0.f;
-                cst[rt][bt] = cn;
+                hn[rt] = (valid && live) ? hr : 0.f;
+                cst[rt][bt] = live ? cn : 0.f;
             }
 #pragma unroll
             for (int rt = 0; rt < RTW; rt++) {
@@ -920,7 +931,7 @@ int launch_lstm_layer_granule(const LstmStepArgs &s, unsigned short *hx, unsigne
     PersistArgs a;
     a.gx = s.gx; a.whh = s.whh_split; a.hx = hx; a.sync = sync; a.err_flag = err_flag;
     a.out = s.out; a.out_raw = s.out_raw; a.out_split = s.out_split; a.oscale = s.oscale; a.oshift = s.oshift;
-    a.T = s.T; a.B = s.B; a.BGr = (s.B + 15) / 16; a.BG = granule_bg(s.B);
+    a.T = s.T; a.B = s.B; a.BGr = (s.B + 15) / 16; a.BG = granule_bg(s.B); a.seqlen = s.seqlen;
     a.dbg = (getenv("MDD_LSTM_DBG") && s.T > 100) ? reinterpret_cast<long long *>(reinterpret_cast<u64 *>(hx) + (size_t)2 * 32 * a.BG * s.H) : nullptr;
     a.early = getenv("MDD_LSTM_EARLY") != nullptr;
     if (a.oscale == nullptr) a.oshift = nullptr;
@@ -973,7 +984,8 @@ int launch_lstm_layer_persistent(const LstmStepArgs &s, unsigned short *hx, unsi
     PersistArgs a;
     a.gx = s.gx; a.whh = s.whh_split; a.hx = hx; a.sync = sync; a.err_flag = err_flag;
     a.out = s.out; a.out_raw = s.out_raw; a.out_split = s.out_split; a.oscale = s.oscale; a.oshift = s.oshift;
-    a.T = s.T; a.B = s.B; a.BGr = (s.B + 7) / 8; a.BG = persistent_bg(s.B);
+    a.T = s.T; a.B = s.B; a.BGr = (s.B + 7) / 8; a.BG = persistent_bg(s.B); a.seqlen = nullptr;
+    if (s.seqlen) { set_error("persistent lstm (counter form): fused batches of different lengths need the granule form"); return MDD_ERR_ARG; }
     a.dbg = (getenv("MDD_LSTM_DBG") && s.T > 100) ? reinterpret_cast<long long *>(hx + (size_t)2 * 16 * 2 * a.BG * s.H) : nullptr;
     a.early = 0;
     const int nbt = a.BG / 16;

@@ -75,6 +75,8 @@ struct LstmStepArgs {
     int packed;          // 1: whh / hbuf / cbuf use the packed consumer layouts of lstm_step_packed_kernel
     float *gates_save = nullptr;   // train mode (generic step kernel only): [T][B][2][H][4] post-activation i,f,g,o
     float *c_save = nullptr;       //                                          [T][B][2][H]    cell state
+    const int *seqlen = nullptr;   // fused batches of different lengths: steps valid per batch row; the REVERSE direction holds h = c = 0 while t >= seqlen[b]
+                                   // (it starts at seqlen[b]-1 with a zero state, as it would in the row's own batch); null = all T steps
 };
 // Enqueue all T steps of one bidirectional layer.
 int launch_lstm_layer(const LstmStepArgs &a, hipStream_t st);
@@ -83,7 +85,8 @@ int launch_embed(const float *table, int rows, int E, const int64_t *ids, int B,
                  int *err_flag, hipStream_t st);
 // softmax over L of S[b][t][:], ctx = A.V, y = BN(cat(X, ctx)), logits = y.Wfc^T, log-softmax
 int launch_attn_tail(const float *S, int Lp, const float *X, const float *V, const float *fscale, const float *fshift,
-                     const float *wfc, const float *wfcp, float *logp, int Tp, int B, int L, int H2, int C, hipStream_t st);
+                     const float *wfc, const float *wfcp, float *logp, int Tp, int B, int L, int H2, int C, hipStream_t st,
+                     const int *llen = nullptr);   // llen[b]: canonical length of b's own batch (softmax / context over l < llen[b]); null = L
 
 int init_kernel_attributes();
 int init_ctc_attributes();

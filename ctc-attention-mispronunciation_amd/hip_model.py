@@ -54,6 +54,24 @@ class HipModel(object):
                 raise IndexError(_lib.lib().mdd_last_error().decode())
         return out
 
+    def forward_fused(self, x, x1, frames, canon, out=None, sync_errors=False):
+        """Several reference batches of different padded lengths in one launch sequence (mdd_forward_fused): x [B,T,F] with every
+        batch zero-padded to the common T, x1 [B,L]; frames [B] int32 = T_g/2 and canon [B] int32 = L_g of each row's own batch.
+        Rows t < frames[b] of the result equal forward() on that batch alone, bit for bit."""
+        assert x.is_cuda and x1.is_cuda and x.dtype == torch.float32 and x1.dtype == torch.int64
+        assert frames.is_cuda and canon.is_cuda and frames.dtype == torch.int32 and canon.dtype == torch.int32
+        x, x1, frames, canon = x.contiguous(), x1.contiguous(), frames.contiguous(), canon.contiguous()
+        B, T, _ = x.shape
+        if out is None:
+            out = torch.empty((T // 2, B, self.geom.num_class), dtype=torch.float32, device=x.device)
+        st = _lib.current_stream_ptr()
+        _lib.check(_lib.lib().mdd_forward_fused(self.handle, C.c_void_p(x.data_ptr()), B, T, C.c_void_p(x1.data_ptr()), x1.shape[1],
+                                                C.c_void_p(frames.data_ptr()), C.c_void_p(canon.data_ptr()), C.c_void_p(out.data_ptr()), st))
+        if sync_errors:
+            if _lib.lib().mdd_sync(self.handle, st) != 0:
+                raise IndexError(_lib.lib().mdd_last_error().decode())
+        return out
+
     def forward_raw(self, raw, x1, out=None, sync_errors=False):
         """raw [B,T_raw,F/3] f32 cuda (unstacked frames), x1 [B,L] i64 cuda -> logp, exactly as
         forward(stack_features(raw), x1): the stack/skip of data_loader.py:138-142 is applied on the fly."""

@@ -90,6 +90,15 @@ int32_t mdd_len_frames(int32_t len, int32_t maxlen, int32_t t_out);
  * (the reference raises IndexError) and are reported by the next mdd_sync(). */
 int mdd_forward(mdd_model *m, const float *x_dev, int32_t B, int32_t T, const int64_t *x1_dev, int32_t L,
                 float *logp_dev, void *stream);
+/* ---- A2-A7 for several reference batches of different padded lengths in ONE launch sequence.  The reference pads each
+ * batch to its own maximum and masks nothing (model_ctc.py:186,198,204-205; collate AA/utils/data_loader.py:151-181), so an
+ * utterance's posteriors depend on its batch's padded length.  frames_dev[b] = T_g / 2 (posterior frames) and canon_dev[b] = L_g
+ * (canonical length) of the batch utterance b belongs to; x_dev [B,T,F] holds every batch zero-padded to the common T (zero from
+ * its own T_g on), x1_dev [B,L] zero-padded to the common L.  Every utterance's rows t < frames_dev[b] of logp_dev [T/2,B,C] are
+ * bit-identical to mdd_forward on its batch alone; rows beyond are undefined. */
+int mdd_forward_fused(mdd_model *m, const float *x_dev, int32_t B, int32_t T, const int64_t *x1_dev, int32_t L,
+                      const int32_t *frames_dev, const int32_t *canon_dev, float *logp_dev, void *stream);
+
 /* ---- A1 + A2..A7 in one call: raw_dev holds the unstacked frames [B, T_raw, feat/3] (make_context(.,0,2) + skip_feat(.,2)
  * + even padding are applied on the fly: AA/utils/tools.py:207-227, AA/utils/data_loader.py:138-142); logp_dev is
  * [mdd_stack_len(T_raw,2,2)/2, B, C].  Same results, bit for bit, as mdd_stack_skip followed by mdd_forward. */

@@ -838,3 +838,83 @@ def test_run_epoch_mirror_trains_and_validates():
     w1 = model.fc[1].weight.detach().clone()
     acc2, loss2 = run_epoch(1, model, batches, loss_fn, "cuda", optimizer=None, is_training=False)
     assert np.isfinite(loss2) and torch.equal(w1, model.fc[1].weight) and not model.training
+
+
+def _ragged_batches(geom, shapes, seed):
+    """Reference-style batches of different padded lengths: [(x [b,T_g,F], x1 [b,L_g], frac)], every utterance zero-padded
+    inside its batch as the collate does (synth_batch ragged=True)."""
+    out = []
+    for k, (b, T, L) in enumerate(shapes):
+        x, x1, frac, _ = synth.synth_batch(geom, B=b, T=T, L=L, seed=seed + 31 * k, ragged=True)
+        out.append((x, x1, frac))
+    return out
+
+
+@pytest.mark.parametrize("precision,lstm", [("bf16x3", None), ("bf16x3", "x3"), ("f32", None)])
+@pytest.mark.parametrize("H", [384, 256])
+def test_fused_batches_of_different_lengths_equal_their_own_runs(precision, lstm, H, monkeypatch):
+    """mdd_forward_fused: batches padded to DIFFERENT lengths T_g / L_g ride one launch sequence; every utterance's posteriors
+    must equal, bit for bit, what mdd_forward gives for its batch alone (the reference masks nothing, so its batch's padded
+    lengths are part of an utterance's result: reverse-direction start, attention over l < L_g).  Persistent BiLSTM, the
+    per-step split-bf16 kernels and the exact-fp32 mode."""
+    if lstm:
+        monkeypatch.setenv("MDD_LSTM", lstm)
+    geom = synth.Geometry(**dict(synth.REFERENCE, hidden=H))
+    sd = synth.synth_state_dict(geom, seed=1234)
+    shapes = [(5, 120, 9), (3, 64, 4), (7, 100, 12), (2, 120, 12), (4, 30, 1)]
+    batches = _ragged_batches(geom, shapes, seed=7)
+    m = _hip().HipModel(geom, sd, precision=precision)
+    alone = [m.forward(_cuda(x), _cuda(x1), sync_errors=True).cpu().numpy() for x, x1, _ in batches]
+    Bt, Tm, Lm = sum(s[0] for s in shapes), max(s[1] for s in shapes), max(s[2] for s in shapes)
+    X = np.zeros((Bt, Tm, geom.feat), dtype=np.float32)
+    X1 = np.zeros((Bt, Lm), dtype=np.int64)
+    frames, canon = np.zeros(Bt, dtype=np.int32), np.zeros(Bt, dtype=np.int32)
+    r = 0
+    for (x, x1, _), (b, T, L) in zip(batches, shapes):
+        X[r:r + b, :T] = x; X1[r:r + b, :L] = x1; frames[r:r + b] = T // 2; canon[r:r + b] = L
+        r += b
+    fused = m.forward_fused(_cuda(X), _cuda(X1), _cuda(frames), _cuda(canon), sync_errors=True).cpu().numpy()
+    r = 0
+    for lp, (b, T, L) in zip(alone, shapes):
+        np.testing.assert_array_equal(fused[:T // 2, r:r + b], lp)
+        r += b
+    again = m.forward_fused(_cuda(X), _cuda(X1), _cuda(frames), _cuda(canon), sync_errors=True).cpu().numpy()
+    np.testing.assert_array_equal(again, fused)
+
+
+def test_fused_batches_full_size_and_reference_golden():
+    """Bench-sized fusion (8 ragged 64-utterance batches, 10 s, the multi-tile persistent BiLSTM): three of the batches checked
+    against their own runs bit for bit; and the G9 reference golden batch (T'=250) riding along with a shorter one still
+    decodes to the reference's strings."""
+    from tests.helpers import chain_inputs
+    geom = synth.Geometry(**synth.REFERENCE)
+    sd = synth.synth_state_dict(geom, seed=1234)
+    rs = np.random.Generator(np.random.PCG64(5))
+    shapes = [(64, int(rs.integers(440, 501)) // 2 * 2, int(rs.integers(20, 41))) for _ in range(8)]
+    batches = _ragged_batches(geom, shapes, seed=99)
+    m = _hip().HipModel(geom, sd, precision="bf16x3")
+    Bt, Tm, Lm = 512, max(s[1] for s in shapes), max(s[2] for s in shapes)
+    X = torch.zeros((Bt, Tm, geom.feat), device="cuda")
+    X1 = torch.zeros((Bt, Lm), dtype=torch.int64, device="cuda")
+    frames, canon = torch.zeros(Bt, dtype=torch.int32, device="cuda"), torch.zeros(Bt, dtype=torch.int32, device="cuda")
+    for g_, ((x, x1, _), (b, T, L)) in enumerate(zip(batches, shapes)):
+        X[64 * g_:64 * g_ + 64, :T] = _cuda(x); X1[64 * g_:64 * g_ + 64, :L] = _cuda(x1)
+        frames[64 * g_:64 * g_ + 64] = T // 2; canon[64 * g_:64 * g_ + 64] = L
+    fused = m.forward_fused(X, X1, frames, canon, sync_errors=True)
+    for g_ in (0, 3, 7):
+        x, x1, _ = batches[g_]
+        own = m.forward(_cuda(x), _cuda(x1), sync_errors=True)
+        assert torch.equal(fused[:shapes[g_][1] // 2, 64 * g_:64 * g_ + 64], own), g_
+    # the reference's own T'=250 batch (G9) fused with a short one
+    meta = jload("g9_chain.json")[0]
+    ref = npz("g9_chain.npz")[meta["tag"] + "_logp"]
+    geom9, sd9, x, x1, frac, _ = chain_inputs(meta)
+    m9 = _hip().HipModel(geom9, sd9, precision="bf16x3")
+    xs, x1s, _ = _ragged_batches(geom9, [(2, 64, 5)], seed=3)[0]
+    B9 = x.shape[0]
+    X = np.zeros((B9 + 2, 500, geom9.feat), dtype=np.float32); X1 = np.zeros((B9 + 2, 40), dtype=np.int64)
+    X[:B9] = x; X1[:B9] = x1; X[B9:, :64] = xs; X1[B9:, :5] = x1s
+    fr = np.array([250] * B9 + [32, 32], dtype=np.int32); cn = np.array([40] * B9 + [5, 5], dtype=np.int32)
+    lp = m9.forward_fused(_cuda(X), _cuda(X1), _cuda(fr), _cuda(cn), sync_errors=True).cpu().numpy()
+    np.testing.assert_allclose(lp[:, :B9], ref, rtol=0, atol=TOL)
+    np.testing.assert_array_equal(lp[:32, B9:], m9.forward(_cuda(xs), _cuda(x1s)).cpu().numpy())
