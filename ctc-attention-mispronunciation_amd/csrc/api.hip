@@ -78,14 +78,13 @@ struct mdd_model {
     int W1() const { return (cfg.feat + 2 - 3) / 2 + 1; }
     int W2() const { return (W1() + 2 - 3) / 2 + 1; }
     int rnn_in() const { return cfg.channels * W2(); }
-    int granule_max_b = 1024;   // MDD_GRANULE_MAXB
-    bool lstm_granule = true;   // persistent kernel with the data-tagged hand-off (MDD_LSTM=counter selects the counter form)
+    int granule_max_b = 1024;   // batch rows the persistent kernel's teams cover (4 row tiles x 16 rows x 16 groups)
     bool lstm_persist = true;   // one persistent team-synchronised launch per BiLSTM layer (split-bf16 mode, >= 256 CUs, B <= 1024)
     int n_cu = 0;
     unsigned int *sync_words = nullptr;
     bool lstm_x3 = false;   // MDD_LSTM=x3: LDS-tiled split-bf16 step kernel (measured slower than the packed fp32 step; kept for study)
     bool conv_fused() const { return x3() && cfg.feat == 243 && cfg.channels == 32; }
-    bool persist(int B) const { return x3() && lstm_persist && !lstm_x3 && B <= (lstm_granule ? granule_max_b : 512); }
+    bool persist(int B) const { return x3() && lstm_persist && !lstm_x3 && B <= granule_max_b; }
     bool x3() const {   // the bf16x3 GEMM needs K % 32 == 0 for every contraction and the packed LSTM layouts
         return precision == 1 && (cfg.hidden == 384 || cfg.hidden == 256) && rnn_in() % 32 == 0 && cfg.emb_dim % 32 == 0;
     }
@@ -256,7 +255,7 @@ static int run_stage(mdd_model *m, int si, const float *x, int B, int T, const i
             a.out_split = x3 ? split_view(m->act_s[n & 1], rows * H2) : kNoSplit;
             a.oscale = m->bn_scale[n + 1]; a.oshift = m->bn_shift[n + 1];
         }
-        if (m->persist(B)) { info->launches = 1; return ((m->lstm_granule && B <= m->granule_max_b) ? launch_lstm_layer_granule : launch_lstm_layer_persistent)(a, reinterpret_cast<unsigned short *>(m->hx.p), m->sync_words, m->err_flag, st); }
+        if (m->persist(B)) { info->launches = 1; return launch_lstm_layer_granule(a, reinterpret_cast<unsigned short *>(m->hx.p), m->sync_words, m->err_flag, st); }
         return launch_lstm_layer(a, st);
     }
     si -= 2 * nl;
@@ -279,7 +278,7 @@ static int run_stage(mdd_model *m, int si, const float *x, int B, int T, const i
         a.T = L; a.B = B; a.H = H; a.packed = use_packed(m);
         a.whh_split = m->t_whh_s; a.hsplit = (x3 && m->lstm_x3) ? reinterpret_cast<unsigned short *>(m->hsplit.p) : nullptr;
         a.seqlen = m->llen;
-        if (m->persist(B)) { info->launches = 1; return ((m->lstm_granule && B <= m->granule_max_b) ? launch_lstm_layer_granule : launch_lstm_layer_persistent)(a, reinterpret_cast<unsigned short *>(m->hx.p), m->sync_words, m->err_flag, st); }
+        if (m->persist(B)) { info->launches = 1; return launch_lstm_layer_granule(a, reinterpret_cast<unsigned short *>(m->hx.p), m->sync_words, m->err_flag, st); }
         return launch_lstm_layer(a, st);
     }
     case 3:
@@ -366,13 +365,10 @@ extern "C" int mdd_create(const mdd_config *cfg, int device, mdd_model **out) {
     const char *lx = getenv("MDD_LSTM");
     m->lstm_x3 = lx && !strcmp(lx, "x3");
     if (lx && !strcmp(lx, "step")) m->lstm_persist = false;
-    if (lx && !strcmp(lx, "counter")) m->lstm_granule = false;
-    if (getenv("MDD_GRANULE_MAXB")) m->granule_max_b = atoi(getenv("MDD_GRANULE_MAXB"));
     const char *g = getenv("MDD_GRAPH");
     m->use_graph = !(g && g[0] == '0');
     if (int rc = init_kernel_attributes()) { delete m; return rc; }
     if (int rc = init_lstm_attributes()) { delete m; return rc; }
-    if (int rc = init_persistent_attributes()) { delete m; return rc; }
     if (int rc = init_granule_attributes()) { delete m; return rc; }
     if (int rc = init_conv_attributes()) { delete m; return rc; }
     if (int rc = init_gemm_attributes()) { delete m; return rc; }
@@ -570,7 +566,7 @@ static int forward_prepare(mdd_model *m, const float *x_dev, int32_t B, int32_t 
                     (rc = ensure(m->act_s[1], rows * 2 * H, zs)) || (rc = ensure(m->x_s, rows * 2 * H, zs)) ||
                     (rc = ensure(m->embo_s, trows * c.emb_dim, zs)) || (rc = ensure(m->text_s, trows * 2 * H, zs)) ||
                     (rc = ensure(m->key_s, trows * 2 * H, zs)) || (rc = ensure(m->hsplit, (size_t)4 * B * H, zs)) ||
-                    (rc = ensure(m->hx, (size_t)2 * 32 * granule_bg(B) * H * 2 + 64 + 256 * 6 * 2, zs))))   // u64 granules (covers the counter form too) + stamps
+                    (rc = ensure(m->hx, (size_t)2 * 32 * granule_bg(B) * H * 2 + 64 + 256 * 6 * 2, zs))))   // u64 granules + stamps
         return rc;
     if (m->taps) {
         m->tap_rnn.resize(c.layers);
@@ -632,9 +628,6 @@ extern "C" int mdd_forward(mdd_model *m, const float *x_dev, int32_t B, int32_t 
 extern "C" int mdd_forward_fused(mdd_model *m, const float *x_dev, int32_t B, int32_t T, const int64_t *x1_dev, int32_t L,
                                  const int32_t *frames_dev, const int32_t *canon_dev, float *logp_dev, void *stream) {
     if (!m || !frames_dev || !canon_dev) { set_error("mdd_forward_fused: null pointer"); return MDD_ERR_ARG; }
-    if (m->finalized && m->persist(B) && !(m->lstm_granule && B <= m->granule_max_b)) {
-        set_error("mdd_forward_fused: needs the granule form of the persistent BiLSTM or the step kernels (MDD_LSTM=counter is not supported)"); return MDD_ERR_ARG;
-    }
     m->tlen = frames_dev; m->llen = canon_dev;
     const int rc = mdd_forward(m, x_dev, B, T, x1_dev, L, logp_dev, stream);
     m->tlen = nullptr; m->llen = nullptr;
@@ -736,8 +729,7 @@ extern "C" const float *mdd_tap(mdd_model *m, const char *name, int64_t *numel) 
         p = dst.p;
     }
     else if (n == "lstm_dbg" && m->hx.p) {   // diagnostic stamps of the last persistent layer launch (MDD_LSTM_DBG=1)
-        p = (m->lstm_granule && B <= m->granule_max_b) ? m->hx.p + (size_t)2 * 32 * granule_bg(B) * m->cfg.hidden * 2
-                            : m->hx.p + (size_t)2 * 16 * 2 * persistent_bg(B) * m->cfg.hidden / 2;
+        p = m->hx.p + (size_t)2 * 32 * granule_bg(B) * m->cfg.hidden * 2;
         ne = 256 * 6 * 2;
     }
     else if (n == "conv1") { p = m->seq0.p; ne = (int64_t)Tp * B * m->rnn_in(); }

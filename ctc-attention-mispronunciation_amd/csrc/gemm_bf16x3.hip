@@ -13,14 +13,16 @@
 // weights are split once at load time), so this kernel moves the same 4 bytes per element an fp32 GEMM
 // would and spends no VALU on conversion.
 //
-// Three kernels share the fragment / swizzle helpers below: LDS-DMA 256x256 (large projections: 48 % of the bf16
-// matrix-core peak, 1.54x the register-staged kernel), LDS-DMA 128x128 (small / batched / split-output GEMMs) and the
-// register-staged 128x128 kernel (MDD_GEMM=regs; kept for the ablation study in tools/gemm_ablation.py).
-// Register-staged tiling: 128x128 block tile, BK = 32, 256 threads = 4 waves (2x2), each wave 64x64 = 2x2 MFMA tiles of
-// 32x32 (64 accumulator VGPRs), 24 MFMAs per wave per K-tile, 2 workgroups per CU.  Four bf16 planes (A hi/lo,
-// W hi/lo) are staged global -> registers -> LDS; loads are issued per PAIR of K-tiles (whole 128-byte lines)
-// one pair ahead of the MFMAs (two LDS stages, one barrier per K-tile).
+// Kernels (all stream their operands HBM -> LDS with LDS-DMA, 16 B per lane, and use v_mfma_f32_16x16x32_bf16 with the WEIGHT
+// fragment as the first operand, so that a lane's four accumulator registers are four consecutive C columns): the 8-phase 256x256
+// kernel (large projections), the single-barrier 256x256 kernel it is screened against, and the 128x128 kernel (small / batched /
+// split-output GEMMs).  An output element is accumulated identically in all of them (batch-size independent bits).  The
+// register-staged and 32x32x16 forms of round 1 measured slower and are no longer built.
+#include <stdlib.h>
 #include <string.h>
+
+#include <algorithm>
+#include <vector>
 
 #include "mdd_internal.h"
 
@@ -36,42 +38,6 @@ constexpr int XPLANE = XBM * XROW;                          // 8192 B
 // (16-lane groups {0-3,12-15,20-27}, ..: rows sharing r&3 differ in (r>>2)&3) and the ds_write_b128 staging writes are
 // bank-conflict-free.
 //
-// Global loads fetch PAIRS of K-tiles: a thread's 16-byte chunk q covers (row q/8, chunk q%8) of a 128-byte line, so 8
-// consecutive lanes read one whole line.  (Fetching one 32-wide K-tile at a time touches half lines whose other half
-// is evicted from the 32 KB L1 before the next K-tile wants it: the kernel is bound by the L2->L1->LDS fill path, not
-// by the matrix cores -- tools/gemm_ablation.py: matrix cores + LDS reads alone 1.15 ms, data movement alone 2.18 ms
-// at M=64000, N=3072, K=1952.)  Chunks 0-3 of a line belong to the even K-tile of the pair, 4-7 to the odd one.
-constexpr int XPL = XBM * 8 / 256;                          // pair-chunks per thread per plane (4)
-
-__device__ __forceinline__ void x3_load_pair(const unsigned short *__restrict__ Ph, const unsigned short *__restrict__ Pl, int ld,
-                                             int rows_total, int K, int row0, int k0, int tid, u32x4 (&rh)[XPL], u32x4 (&rl)[XPL]) {
-    // branch-free: rows past the edge are clamped (their products land in C rows/cols that are never stored); chunks past
-    // K (K % 64 == 32 tails) read a valid address and are zeroed
-#pragma unroll
-    for (int i = 0; i < XPL; i++) {
-        const int q = tid + 256 * i, row = min(row0 + (q >> 3), rows_total - 1), k = k0 + (q & 7) * 8;
-        const size_t off = (size_t)row * ld + min(k, K - 8);
-        const u32x4 vh = *reinterpret_cast<const u32x4 *>(Ph + off), vl = *reinterpret_cast<const u32x4 *>(Pl + off);
-        const u32x4 z = {0u, 0u, 0u, 0u};
-        rh[i] = k < K ? vh : z;
-        rl[i] = k < K ? vl : z;
-    }
-}
-
-// store the even (odd = 0) or odd (odd = 1) K-tile of a loaded pair into one LDS stage: lanes whose chunk belongs to the
-// other half skip the write (q & 4 selects the half; 4 consecutive lanes = 64 contiguous bytes of a row)
-__device__ __forceinline__ void x3_store_half(unsigned char *ph, unsigned char *pl, int tid, int odd, const u32x4 (&rh)[XPL], const u32x4 (&rl)[XPL]) {
-#pragma unroll
-    for (int i = 0; i < XPL; i++) {
-        const int q = tid + 256 * i, row = q >> 3, c8 = q & 7;
-        if ((c8 >> 2) == odd) {
-            const int off = row * XROW + (((c8 & 3) ^ ((row >> 2) & 3)) << 4);
-            *reinterpret_cast<u32x4 *>(ph + off) = rh[i];
-            *reinterpret_cast<u32x4 *>(pl + off) = rl[i];
-        }
-    }
-}
-
 __device__ __forceinline__ bf16x8 x3_frag(const unsigned char *plane, int row, int kbyte) {
     return *reinterpret_cast<const bf16x8 *>(plane + row * XROW + ((((kbyte >> 4) ^ ((row >> 2) & 3))) << 4));
 }
@@ -81,131 +47,6 @@ __device__ __forceinline__ unsigned short bf16_bits(float x) {   // round-to-nea
     return *reinterpret_cast<unsigned short *>(&b);
 }
 __device__ __forceinline__ float bf16_to_f32(unsigned short b) { return __uint_as_float((unsigned)b << 16); }
-
-// EPI 0: fp32 C (+bias).  EPI 1: split-bf16 C (hi/lo planes, same ldc).  ABL: ablation bits for tools/gemm_ablation.py
-// (1: no MFMA, 2: no global loads in the loop, 4: no LDS stores in the loop); 0 in the product.
-template <int EPI, int ABL = 0>
-__global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(const unsigned short *__restrict__ Ah, const unsigned short *__restrict__ Al,
-                                                              const unsigned short *__restrict__ Wh, const unsigned short *__restrict__ Wl,
-                                                              const float *__restrict__ bias, float *__restrict__ C,
-                                                              unsigned short *__restrict__ Ch, unsigned short *__restrict__ Cl, int M, int N,
-                                                              int K, int lda, int ldw, int ldc, long sA, long sW, long sC, int tiles_n) {
-    __shared__ __attribute__((aligned(16))) unsigned char lds[2][4][XPLANE];   // [stage][Ah,Al,Wh,Wl]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-    int nwg = gridDim.x, bid = blockIdx.x;
-    int q = nwg >> 3, rem = nwg & 7, xcd = bid & 7;   // XCD-aware tile order (see gemm.hip)
-    int swz = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + (bid >> 3);
-    const int tm = swz / tiles_n, tn = swz % tiles_n;
-    const int m0 = tm * XBM, n0 = tn * XBN;
-    Ah += (size_t)blockIdx.z * sA; Al += (size_t)blockIdx.z * sA;
-    Wh += (size_t)blockIdx.z * sW; Wl += (size_t)blockIdx.z * sW;
-
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; i++)
-#pragma unroll
-        for (int j = 0; j < 2; j++)
-#pragma unroll
-            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
-
-    const int nk = (K + XBK - 1) / XBK;
-    const int li = lane & 31, kb = (lane >> 5) * 16;
-    auto compute = [&](int cur) {
-#pragma unroll
-        for (int ks = 0; ks < 2; ks++) {
-            bf16x8 fah[2], fal[2], fwh[2], fwl[2];
-#pragma unroll
-            for (int i = 0; i < 2; i++) {
-                fah[i] = x3_frag(lds[cur][0], wm * 64 + i * 32 + li, ks * 32 + kb);
-                fal[i] = x3_frag(lds[cur][1], wm * 64 + i * 32 + li, ks * 32 + kb);
-                fwh[i] = x3_frag(lds[cur][2], wn * 64 + i * 32 + li, ks * 32 + kb);
-                fwl[i] = x3_frag(lds[cur][3], wn * 64 + i * 32 + li, ks * 32 + kb);
-            }
-            if (ABL & 1) {   // ablation: keep the fragment reads alive, skip the matrix cores
-#pragma unroll
-                for (int i = 0; i < 2; i++) asm volatile("" :: "v"(fah[i]), "v"(fal[i]), "v"(fwh[i]), "v"(fwl[i]));
-                continue;
-            }
-#pragma unroll
-            for (int i = 0; i < 2; i++)
-#pragma unroll
-                for (int j = 0; j < 2; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fah[i], fwl[j], acc[i][j], 0, 0, 0);
-#pragma unroll
-            for (int i = 0; i < 2; i++)
-#pragma unroll
-                for (int j = 0; j < 2; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fal[i], fwh[j], acc[i][j], 0, 0, 0);
-#pragma unroll
-            for (int i = 0; i < 2; i++)
-#pragma unroll
-                for (int j = 0; j < 2; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fah[i], fwh[j], acc[i][j], 0, 0, 0);
-        }
-    };
-
-    // Pipeline over K-tile PAIRS, two register sets (P, Q), loop unrolled by two pairs so both are addressed statically.
-    // Entering the loop body for pair p (tiles 2p, 2p+1): set P holds pair p, LDS stage 0 holds tile 2p.
-    //   issue loads of pair p+1 into Q | compute tile 2p | store tile 2p+1 (P, odd half) -> stage 1 | barrier
-    //   compute tile 2p+1 | store tile 2p+2 (Q, even half) -> stage 0 | barrier            then P <-> Q
-    u32x4 pah[XPL], pal[XPL], pwh[XPL], pwl[XPL], qah[XPL], qal[XPL], qwh[XPL], qwl[XPL];
-    const int npair = (nk + 1) / 2;
-    x3_load_pair(Ah, Al, lda, M, K, m0, 0, tid, pah, pal);
-    x3_load_pair(Wh, Wl, ldw, N, K, n0, 0, tid, pwh, pwl);
-    x3_store_half(lds[0][0], lds[0][1], tid, 0, pah, pal);
-    x3_store_half(lds[0][2], lds[0][3], tid, 0, pwh, pwl);
-    __syncthreads();
-#define X3_PAIR_STEP(P_AH, P_AL, P_WH, P_WL, Q_AH, Q_AL, Q_WH, Q_WL, p)                                   \
-    {                                                                                                     \
-        const bool more = (p) + 1 < npair, odd_tile = 2 * (p) + 1 < nk;                                   \
-        if (more && !(ABL & 2)) {                                                                         \
-            x3_load_pair(Ah, Al, lda, M, K, m0, ((p) + 1) * 2 * XBK, tid, Q_AH, Q_AL);                    \
-            x3_load_pair(Wh, Wl, ldw, N, K, n0, ((p) + 1) * 2 * XBK, tid, Q_WH, Q_WL);                    \
-        }                                                                                                 \
-        compute(0);                                                                                       \
-        if (odd_tile && !(ABL & 4)) {                                                                     \
-            x3_store_half(lds[1][0], lds[1][1], tid, 1, P_AH, P_AL);                                      \
-            x3_store_half(lds[1][2], lds[1][3], tid, 1, P_WH, P_WL);                                      \
-        }                                                                                                 \
-        __syncthreads();                                                                                  \
-        if (odd_tile) {                                                                                   \
-            compute(1);                                                                                   \
-            if (more && !(ABL & 4)) {                                                                     \
-                x3_store_half(lds[0][0], lds[0][1], tid, 0, Q_AH, Q_AL);                                  \
-                x3_store_half(lds[0][2], lds[0][3], tid, 0, Q_WH, Q_WL);                                  \
-            }                                                                                             \
-            __syncthreads();                                                                              \
-        }                                                                                                 \
-    }
-    for (int p = 0; p < npair; p += 2) {
-        X3_PAIR_STEP(pah, pal, pwh, pwl, qah, qal, qwh, qwl, p)
-        if (p + 1 < npair) X3_PAIR_STEP(qah, qal, qwh, qwl, pah, pal, pwh, pwl, p + 1)
-    }
-#undef X3_PAIR_STEP
-
-    // epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-    const int lh = lane >> 5;
-    if (EPI == 0) C += (size_t)blockIdx.z * sC; else { Ch += (size_t)blockIdx.z * sC; Cl += (size_t)blockIdx.z * sC; }
-#pragma unroll
-    for (int i = 0; i < 2; i++)
-#pragma unroll
-        for (int j = 0; j < 2; j++) {
-            const int col = n0 + wn * 64 + j * 32 + li;
-            if (col >= N) continue;
-            const float bv = bias ? bias[col] : 0.f;
-#pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (row >= M) continue;
-                const float v = acc[i][j][r] + bv;
-                if (EPI == 0) C[(size_t)row * ldc + col] = v;
-                else {
-                    const unsigned short h = bf16_bits(v);
-                    Ch[(size_t)row * ldc + col] = h;
-                    Cl[(size_t)row * ldc + col] = bf16_bits(v - bf16_to_f32(h));
-                }
-            }
-        }
-}
-
 // ---- LDS-DMA variant of the 128x128 kernel: tiles go global -> LDS directly (global_load_lds_dwordx4), no staging
 // registers and no ds_write pass.  The LDS image is lane-linear per wave-instruction (64 x 16 B = 16 rows of one plane),
 // so the XOR swizzle is applied to the per-lane SOURCE address; fragment reads use the same swizzle (x3_frag).
@@ -271,28 +112,27 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_glds_kernel(const unsigned
             const bf16x8 fah = x3_frag(st, wm * 64 + i * 16 + l16, kq16);
             const bf16x8 fal = x3_frag(st + XPLANE, wm * 64 + i * 16 + l16, kq16);
 #pragma unroll
-            for (int j = 0; j < 4; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fah, fwl[j], acc[i][j], 0, 0, 0);
+            for (int j = 0; j < 4; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fwl[j], fah, acc[i][j], 0, 0, 0);
 #pragma unroll
-            for (int j = 0; j < 4; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fal, fwh[j], acc[i][j], 0, 0, 0);
+            for (int j = 0; j < 4; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fwh[j], fal, acc[i][j], 0, 0, 0);
 #pragma unroll
-            for (int j = 0; j < 4; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fah, fwh[j], acc[i][j], 0, 0, 0);
+            for (int j = 0; j < 4; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fwh[j], fah, acc[i][j], 0, 0, 0);
         }
         __syncthreads();
     }
-    const int q4 = (lane >> 4) * 4;   // 16x16 C/D: col = lane&15, row = 4*(lane>>4) + r
+    const int q4 = (lane >> 4) * 4;   // W fragment first: D row = 4*(lane>>4) + r = C column, D col = lane&15 = C row
     if (EPI == 0) C += (size_t)blockIdx.z * sC; else { Ch += (size_t)blockIdx.z * sC; Cl += (size_t)blockIdx.z * sC; }
 #pragma unroll
     for (int i = 0; i < 4; i++)
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-            const int col = n0 + wn * 64 + j * 16 + l16;
-            if (col >= N) continue;
-            const float bv = bias ? bias[col] : 0.f;
+            const int row = m0 + wm * 64 + i * 16 + l16;
+            if (row >= M) continue;
 #pragma unroll
             for (int r = 0; r < 4; r++) {
-                const int row = m0 + wm * 64 + i * 16 + q4 + r;
-                if (row >= M) continue;
-                const float v = acc[i][j][r] + bv;
+                const int col = n0 + wn * 64 + j * 16 + q4 + r;
+                if (col >= N) continue;
+                const float v = acc[i][j][r] + (bias ? bias[col] : 0.f);
                 if (EPI == 0) C[(size_t)row * ldc + col] = v;
                 else {
                     const unsigned short h = bf16_bits(v);
@@ -304,7 +144,6 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_glds_kernel(const unsigned
 }
 
 // ---- LDS-DMA, 256x256 tile, 8 waves (2 x 4), per wave 128x64: half the L2 -> LDS bytes per flop of the 128x128 tile.
-template <int SHAPE>
 __global__ __launch_bounds__(512, 2) void gemm_bf16x3_glds256_kernel(const unsigned short *__restrict__ Ah, const unsigned short *__restrict__ Al,
                                                                       const unsigned short *__restrict__ Wh, const unsigned short *__restrict__ Wl,
                                                                       const float *__restrict__ bias, float *__restrict__ C, int M, int N, int K,
@@ -318,23 +157,12 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16x3_glds256_kernel(const unsig
     int swz = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + (bid >> 3);
     const int tm = swz / tiles_n, tn = swz % tiles_n;
     const int m0 = tm * 256, n0 = tn * 256;
-
     typedef float f32x4 __attribute__((ext_vector_type(4)));
-    f32x16 acc[4][2];
     f32x4 acc16[8][4];
-    if (SHAPE == 0) {
 #pragma unroll
-        for (int i = 0; i < 4; i++)
+    for (int i = 0; i < 8; i++)
 #pragma unroll
-            for (int j = 0; j < 2; j++)
-#pragma unroll
-                for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
-    } else {
-#pragma unroll
-        for (int i = 0; i < 8; i++)
-#pragma unroll
-            for (int j = 0; j < 4; j++) acc16[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    }
+        for (int j = 0; j < 4; j++) acc16[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     auto fill = [&](int k0, unsigned char *stage, int j0 = 0, int j1 = 8) {
 #pragma unroll
         for (int j = j0; j < j1; j++) {
@@ -347,100 +175,60 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16x3_glds256_kernel(const unsig
         }
     };
     const int nk = K / XBK;
-    const int li = lane & 31, kb = (lane >> 5) * 16;
     fill(0, glds_smem);
     __syncthreads();
     for (int kt = 0; kt < nk; kt++) {
         const int cur = kt & 1;
         const bool more = kt + 1 < nk;
         unsigned char *nst = glds_smem + (cur ^ 1) * 4 * PL;
-        if (SHAPE == 0 && more) fill((kt + 1) * XBK, nst);
         const unsigned char *st = glds_smem + cur * 4 * PL;
-        if (SHAPE == 0) {
+        // v_mfma_f32_16x16x32_bf16: one k-step per K-tile; lane (row l&15, k-slice l>>4)
+        const int l16 = lane & 15, kq16 = (lane >> 4) * 16;
+        bf16x8 fwh[4], fwl[4];
 #pragma unroll
-            for (int ks = 0; ks < 2; ks++) {
-                bf16x8 fwh[2], fwl[2];
+        for (int j = 0; j < 4; j++) {
+            fwh[j] = x3_frag(st + 2 * PL, wn * 64 + j * 16 + l16, kq16);
+            fwl[j] = x3_frag(st + 3 * PL, wn * 64 + j * 16 + l16, kq16);
+        }
+        // the next stage's 8 LDS-DMA pieces go out two at a time between the MFMA groups: a piece costs the issuing
+        // wave 100+ cycles, which the SIMD's other wave covers with MFMAs only if the two are not doing it at once
 #pragma unroll
-                for (int j = 0; j < 2; j++) {
-                    fwh[j] = x3_frag(st + 2 * PL, wn * 64 + j * 32 + li, ks * 32 + kb);
-                    fwl[j] = x3_frag(st + 3 * PL, wn * 64 + j * 32 + li, ks * 32 + kb);
-                }
-#pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    const bf16x8 fah = x3_frag(st, wm * 128 + i * 32 + li, ks * 32 + kb);
-                    const bf16x8 fal = x3_frag(st + PL, wm * 128 + i * 32 + li, ks * 32 + kb);
-#pragma unroll
-                    for (int j = 0; j < 2; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fah, fwl[j], acc[i][j], 0, 0, 0);
-#pragma unroll
-                    for (int j = 0; j < 2; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fal, fwh[j], acc[i][j], 0, 0, 0);
-#pragma unroll
-                    for (int j = 0; j < 2; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fah, fwh[j], acc[i][j], 0, 0, 0);
-                }
+        for (int i = 0; i < 8; i++) {
+            if ((i & 1) == 0) {
+                if (more) fill((kt + 1) * XBK, nst, i, i + 2);
+                __builtin_amdgcn_sched_barrier(0);
             }
-        } else {   // v_mfma_f32_16x16x32_bf16: one k-step per K-tile; lane (row l&15, k-slice l>>4)
-            const int l16 = lane & 15, kq16 = (lane >> 4) * 16;
-            bf16x8 fwh[4], fwl[4];
+            const bf16x8 fah = x3_frag(st, wm * 128 + i * 16 + l16, kq16);
+            const bf16x8 fal = x3_frag(st + PL, wm * 128 + i * 16 + l16, kq16);
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
-                fwh[j] = x3_frag(st + 2 * PL, wn * 64 + j * 16 + l16, kq16);
-                fwl[j] = x3_frag(st + 3 * PL, wn * 64 + j * 16 + l16, kq16);
-            }
-            // the next stage's 8 LDS-DMA pieces go out two at a time between the MFMA groups: a piece costs the issuing
-            // wave 100+ cycles, which the SIMD's other wave covers with MFMAs only if the two are not doing it at once
+            for (int j = 0; j < 4; j++) acc16[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fwl[j], fah, acc16[i][j], 0, 0, 0);
 #pragma unroll
-            for (int i = 0; i < 8; i++) {
-                if ((i & 1) == 0) {
-                    if (more) fill((kt + 1) * XBK, nst, i, i + 2);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-                const bf16x8 fah = x3_frag(st, wm * 128 + i * 16 + l16, kq16);
-                const bf16x8 fal = x3_frag(st + PL, wm * 128 + i * 16 + l16, kq16);
+            for (int j = 0; j < 4; j++) acc16[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fwh[j], fal, acc16[i][j], 0, 0, 0);
 #pragma unroll
-                for (int j = 0; j < 4; j++) acc16[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fah, fwl[j], acc16[i][j], 0, 0, 0);
-#pragma unroll
-                for (int j = 0; j < 4; j++) acc16[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fal, fwh[j], acc16[i][j], 0, 0, 0);
-#pragma unroll
-                for (int j = 0; j < 4; j++) acc16[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fah, fwh[j], acc16[i][j], 0, 0, 0);
-                if (i & 1) __builtin_amdgcn_sched_barrier(0);
-            }
+            for (int j = 0; j < 4; j++) acc16[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fwh[j], fah, acc16[i][j], 0, 0, 0);
+            if (i & 1) __builtin_amdgcn_sched_barrier(0);
         }
         __syncthreads();
     }
-    if (SHAPE == 0) {
-        const int lh = lane >> 5;
-#pragma unroll
-        for (int i = 0; i < 4; i++)
-#pragma unroll
-            for (int j = 0; j < 2; j++) {
-                const int col = n0 + wn * 64 + j * 32 + li;
-                if (col >= N) continue;
-                const float bv = bias ? bias[col] : 0.f;
-#pragma unroll
-                for (int r = 0; r < 16; r++) {
-                    const int row = m0 + wm * 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    if (row < M) C[(size_t)row * ldc + col] = acc[i][j][r] + bv;
-                }
-            }
-    } else {   // 16x16 C/D: col = lane&15, row = 4*(lane>>4) + r
+    {   // W fragment first: D row = 4*(lane>>4) + r = C column, D col = lane&15 = C row (see the 8-phase kernel)
         const int l16 = lane & 15, q4 = (lane >> 4) * 4;
 #pragma unroll
         for (int i = 0; i < 8; i++)
 #pragma unroll
             for (int j = 0; j < 4; j++) {
-                const int col = n0 + wn * 64 + j * 16 + l16;
-                if (col >= N) continue;
-                const float bv = bias ? bias[col] : 0.f;
+                const int row = m0 + wm * 128 + i * 16 + l16;
+                if (row >= M) continue;
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
-                    const int row = m0 + wm * 128 + i * 16 + q4 + r;
-                    if (row < M) C[(size_t)row * ldc + col] = acc16[i][j][r] + bv;
+                    const int col = n0 + wn * 64 + j * 16 + q4 + r;
+                    if (col < N) C[(size_t)row * ldc + col] = acc16[i][j][r] + (bias ? bias[col] : 0.f);
                 }
             }
     }
 }
 
 // ---- 256x256 tile, eight barrier-delimited phases per K-tile, two wave groups one barrier apart.
-// Same LDS image and the same per-element arithmetic as gemm_bf16x3_glds256_kernel<1> (identical bits); what changes is
+// Same LDS image and the same per-element arithmetic as gemm_bf16x3_glds256_kernel (identical bits); what changes is
 // who waits for what.  The K-tile's operands are four half-tiles (A rows 0..127 / 128..255, W rows 0..127 / 128..255;
 // hi + lo planes, 16 KB = 16 LDS-DMA pieces = 2 per wave) and a wave's share of C is four 64x32 quadrants (A half a,
 // W half b) taken in the order (0,0) (0,1) (1,1) (1,0).  A quadrant is a load phase L (fragment reads for it, the two
@@ -451,10 +239,15 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16x3_glds256_kernel(const unsig
 // Hazards: a half-tile issued in phase p is waited for at the end of L(p+2) by every wave, read in L(p+3) -- for the
 // late group that is after one more barrier than the early group's wait, as the stagger requires -- and its buffer is
 // refilled eight phases later.
+template <bool DMA_IN_M, bool STAMP = false>
 __global__ __launch_bounds__(512, 2) void gemm_bf16x3_ph8_kernel(const unsigned short *__restrict__ Ah, const unsigned short *__restrict__ Al,
                                                                  const unsigned short *__restrict__ Wh, const unsigned short *__restrict__ Wl,
                                                                  const float *__restrict__ bias, float *__restrict__ C, int M, int N, int K,
-                                                                 int lda, int ldw, int ldc, int tiles_n) {
+                                                                 int lda, int ldw, int ldc, int tiles_n, long long *stamps = nullptr) {
+    // STAMP (diagnostic build only): per wave, cycles spent in load-phase bodies / waiting at their barrier / MFMA-phase bodies /
+    // waiting at theirs, summed over the K loop -> stamps[(workgroup * 8 + wave) * 4 + {0,1,2,3}]
+    long long sacc[4] = {0, 0, 0, 0}, stt = 0;
+#define PH8_T(i_) do { if (STAMP) { const long long n_ = (long long)__builtin_readcyclecounter(); sacc[i_] += n_ - stt; stt = n_; } } while (0)
     extern __shared__ __attribute__((aligned(16))) unsigned char glds_smem[];   // [2 stages][Ah|Al|Wh|Wl][256 rows x 64 B] = 128 KB
     constexpr int PL = 256 * XROW;                                              // 16 KB per plane
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -505,16 +298,34 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16x3_ph8_kernel(const unsigned 
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     if (grp == 1) asm volatile("s_barrier" ::: "memory");            // from here on one barrier behind group 0
     bf16x8 fah[4], fal[4], fwh[2][2], fwl[2][2];                     // A fragments of the current half; W fragments of both halves
-#define PH8_END_L() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); __builtin_amdgcn_s_setprio(1)
-#define PH8_END_M() __builtin_amdgcn_s_setprio(0); asm volatile("s_barrier" ::: "memory")
+#define PH8_END_L() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); PH8_T(0); asm volatile("s_barrier" ::: "memory"); PH8_T(1); __builtin_amdgcn_s_setprio(1)
+#define PH8_END_M() __builtin_amdgcn_s_setprio(0); PH8_T(2); asm volatile("s_barrier" ::: "memory"); PH8_T(3)
 #define PH8_LOAD_A(a_) _Pragma("unroll") for (int i = 0; i < 4; i++) { \
             fah[i] = x3_frag(st, (a_) * 128 + wr * 64 + i * 16 + l16, kq16); fal[i] = x3_frag(st + PL, (a_) * 128 + wr * 64 + i * 16 + l16, kq16); }
 #define PH8_LOAD_W(b_) _Pragma("unroll") for (int j = 0; j < 2; j++) { \
             fwh[b_][j] = x3_frag(st + 2 * PL, (b_) * 128 + wc * 32 + j * 16 + l16, kq16); fwl[b_][j] = x3_frag(st + 3 * PL, (b_) * 128 + wc * 32 + j * 16 + l16, kq16); }
 #define PH8_MFMA(a_, b_) _Pragma("unroll") for (int i = 0; i < 4; i++) { \
-            _Pragma("unroll") for (int j = 0; j < 2; j++) acc[a_][b_][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fah[i], fwl[b_][j], acc[a_][b_][i][j], 0, 0, 0); \
-            _Pragma("unroll") for (int j = 0; j < 2; j++) acc[a_][b_][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fal[i], fwh[b_][j], acc[a_][b_][i][j], 0, 0, 0); \
-            _Pragma("unroll") for (int j = 0; j < 2; j++) acc[a_][b_][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fah[i], fwh[b_][j], acc[a_][b_][i][j], 0, 0, 0); }
+            _Pragma("unroll") for (int j = 0; j < 2; j++) acc[a_][b_][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fwl[b_][j], fah[i], acc[a_][b_][i][j], 0, 0, 0); \
+            _Pragma("unroll") for (int j = 0; j < 2; j++) acc[a_][b_][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fwh[b_][j], fal[i], acc[a_][b_][i][j], 0, 0, 0); \
+            _Pragma("unroll") for (int j = 0; j < 2; j++) acc[a_][b_][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fwh[b_][j], fah[i], acc[a_][b_][i][j], 0, 0, 0); }
+    // DMA_IN_M (experiment, not the default): the two LDS-DMA pieces of a phase pair are issued from inside the MFMA phase (behind
+    // its first MFMA group) instead of from the load phase; each counted wait then sees one issue less in front of it (vmcnt(2) where
+    // the load-phase form has vmcnt(4)).  Stamps (profiles/round2_gemm_phase_stamps.txt): the MFMA phases, not the load phases, set
+    // the length of a barrier interval (per K-tile and wave: MFMA bodies 1744 cycles against load bodies 1336), so moving issue work
+    // into them lengthens the interval: 5-8 % slower.
+#define PH8_MFMA_DMA(a_, b_, ht_) do { if (DMA_IN_M) { \
+            _Pragma("unroll") for (int j = 0; j < 2; j++) acc[a_][b_][0][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fwl[b_][j], fah[0], acc[a_][b_][0][j], 0, 0, 0); \
+            _Pragma("unroll") for (int j = 0; j < 2; j++) acc[a_][b_][0][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fwh[b_][j], fal[0], acc[a_][b_][0][j], 0, 0, 0); \
+            _Pragma("unroll") for (int j = 0; j < 2; j++) acc[a_][b_][0][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fwh[b_][j], fah[0], acc[a_][b_][0][j], 0, 0, 0); \
+            __builtin_amdgcn_sched_barrier(0); \
+            if (more) issue(ht_, nk0, nst); \
+            __builtin_amdgcn_sched_barrier(0); \
+            _Pragma("unroll") for (int i = 1; i < 4; i++) { \
+            _Pragma("unroll") for (int j = 0; j < 2; j++) acc[a_][b_][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fwl[b_][j], fah[i], acc[a_][b_][i][j], 0, 0, 0); \
+            _Pragma("unroll") for (int j = 0; j < 2; j++) acc[a_][b_][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fwh[b_][j], fal[i], acc[a_][b_][i][j], 0, 0, 0); \
+            _Pragma("unroll") for (int j = 0; j < 2; j++) acc[a_][b_][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fwh[b_][j], fah[i], acc[a_][b_][i][j], 0, 0, 0); } \
+        } else { PH8_MFMA(a_, b_) } } while (0)
+    if (STAMP) stt = (long long)__builtin_readcyclecounter();
     for (int kt = 0; kt < nk; kt++) {
         const unsigned char *st = glds_smem + (kt & 1) * 4 * PL;
         const unsigned nst = (unsigned)(((kt & 1) ^ 1) * 4 * PL);   // byte offset of the other stage
@@ -522,46 +333,63 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16x3_ph8_kernel(const unsigned 
         const int nk0 = (kt + 1) * XBK;
         // ---- quadrant (0,0)
         PH8_LOAD_A(0) PH8_LOAD_W(0)
-        if (more) issue(0, nk0, nst);
-        if (more) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");   // W1 of this K-tile
+        if (DMA_IN_M) {
+            asm volatile("s_waitcnt vmcnt(2)" ::: "memory");                                                              // W1 of this K-tile
+        } else {
+            if (more) issue(0, nk0, nst);
+            if (more) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");   // W1 of this K-tile
+        }
         __builtin_amdgcn_sched_barrier(0);
         PH8_END_L();
-        PH8_MFMA(0, 0)
+        PH8_MFMA_DMA(0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
         PH8_END_M();
         // ---- quadrant (0,1)
         PH8_LOAD_W(1)
-        if (more) issue(1, nk0, nst);
-        if (more) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // A1 of this K-tile
+        if (DMA_IN_M) {
+            if (more) asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // A1 of this K-tile
+        } else {
+            if (more) issue(1, nk0, nst);
+            if (more) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // A1 of this K-tile
+        }
         __builtin_amdgcn_sched_barrier(0);
         PH8_END_L();
-        PH8_MFMA(0, 1)
+        PH8_MFMA_DMA(0, 1, 1);
         __builtin_amdgcn_sched_barrier(0);
         PH8_END_M();
         // ---- quadrant (1,1)
         PH8_LOAD_A(1)
-        if (more) issue(2, nk0, nst);
+        if (!DMA_IN_M && more) issue(2, nk0, nst);
         __builtin_amdgcn_sched_barrier(0);
         PH8_END_L();
-        PH8_MFMA(1, 1)
+        PH8_MFMA_DMA(1, 1, 2);
         __builtin_amdgcn_sched_barrier(0);
         PH8_END_M();
         // ---- quadrant (1,0): its fragments are already in registers
-        if (more) { issue(3, nk0, nst); asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }   // A0, W0 of the next K-tile
+        if (DMA_IN_M) {
+            if (more) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");                                                  // A0, W0 of the next K-tile
+        } else if (more) { issue(3, nk0, nst); asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }                        // A0, W0 of the next K-tile
         __builtin_amdgcn_sched_barrier(0);
         PH8_END_L();
-        PH8_MFMA(1, 0)
+        PH8_MFMA_DMA(1, 0, 3);
         __builtin_amdgcn_sched_barrier(0);
         PH8_END_M();
     }
+#undef PH8_MFMA_DMA
+    if (STAMP && stamps && lane == 0 && blockIdx.x < 256)
+        for (int i = 0; i < 4; i++) stamps[((size_t)blockIdx.x * 8 + wave) * 4 + i] = sacc[i];
+#undef PH8_T
 #undef PH8_END_L
 #undef PH8_END_M
 #undef PH8_LOAD_A
 #undef PH8_LOAD_W
 #undef PH8_MFMA
     if (grp == 0) asm volatile("s_barrier" ::: "memory");            // pairs with group 1's last barrier
-    // 16x16 C/D: col = lane&15, row = 4*(lane>>4) + r
+    // The W fragment is the MFMA's first operand (D rows = weight rows = C columns) and the A fragment its second (D columns = C
+    // rows): D row = 4*(lane>>4) + r, D col = lane&15, so a lane's four accumulator registers are FOUR CONSECUTIVE COLUMNS of one C
+    // row -- the tile leaves as 16-byte stores (32 per wave, 16 rows x 64 B each) instead of 128 scalar ones.
     const int q4 = (lane >> 4) * 4;
+    const bool n_vec = (ldc % 4 == 0) && (((size_t)C & 15) == 0);
 #pragma unroll
     for (int a = 0; a < 2; a++)
 #pragma unroll
@@ -570,115 +398,63 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16x3_ph8_kernel(const unsigned 
             for (int i = 0; i < 4; i++)
 #pragma unroll
                 for (int j = 0; j < 2; j++) {
-                    const int col = n0 + b * 128 + wc * 32 + j * 16 + l16;
-                    if (col >= N) continue;
-                    const float bv = bias ? bias[col] : 0.f;
+                    const int row = m0 + a * 128 + wr * 64 + i * 16 + l16;
+                    const int col = n0 + b * 128 + wc * 32 + j * 16 + q4;
+                    if (row >= M || col >= N) continue;
+                    const f32x4 v = acc[a][b][i][j];
+                    float *dst = C + (size_t)row * ldc + col;
+                    if (n_vec && col + 3 < N) {
+                        float4 o = make_float4(v[0], v[1], v[2], v[3]);
+                        if (bias) { const float4 bv = *reinterpret_cast<const float4 *>(bias + col); o.x += bv.x; o.y += bv.y; o.z += bv.z; o.w += bv.w; }
+                        *reinterpret_cast<float4 *>(dst) = o;
+                    } else {
 #pragma unroll
-                    for (int r = 0; r < 4; r++) {
-                        const int row = m0 + a * 128 + wr * 64 + i * 16 + q4 + r;
-                        if (row < M) C[(size_t)row * ldc + col] = acc[a][b][i][j][r] + bv;
+                        for (int r = 0; r < 4; r++) if (col + r < N) dst[r] = v[r] + (bias ? bias[col + r] : 0.f);
                     }
                 }
 }
 
 int init_gemm_attributes() {
-    MDD_HIP_CHECK(hipFuncSetAttribute((const void *)gemm_bf16x3_glds256_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 4 * 256 * XROW));
-    MDD_HIP_CHECK(hipFuncSetAttribute((const void *)gemm_bf16x3_glds256_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 4 * 256 * XROW));
-    MDD_HIP_CHECK(hipFuncSetAttribute((const void *)gemm_bf16x3_ph8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 4 * 256 * XROW));
+    MDD_HIP_CHECK(hipFuncSetAttribute((const void *)gemm_bf16x3_glds256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 4 * 256 * XROW));
+    MDD_HIP_CHECK(hipFuncSetAttribute((const void *)gemm_bf16x3_ph8_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 4 * 256 * XROW));
+    MDD_HIP_CHECK(hipFuncSetAttribute((const void *)gemm_bf16x3_ph8_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 4 * 256 * XROW));
+    MDD_HIP_CHECK(hipFuncSetAttribute((const void *)(gemm_bf16x3_ph8_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 4 * 256 * XROW));
+    MDD_HIP_CHECK(hipFuncSetAttribute((const void *)(gemm_bf16x3_ph8_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 4 * 256 * XROW));
     return MDD_OK;
 }
 
 int launch_gemm_bf16x3(const SplitPtr &A, const SplitPtr &W, const float *bias, float *C, const SplitPtr *Csplit, int M, int N,
                        int K, int lda, int ldw, int ldc, int batch, long sA, long sW, long sC, hipStream_t st) {
-    if (M <= 0 || N <= 0 || K <= 0 || batch <= 0 || K % 8 || lda % 8 || ldw % 8 || sA % 8 || sW % 8) {
-        set_error("gemm_bf16x3: bad shape M=%d N=%d K=%d lda=%d ldw=%d", M, N, K, lda, ldw);
+    if (M <= 0 || N <= 0 || K <= 0 || batch <= 0 || K % XBK || lda % 8 || ldw % 8 || sA % 8 || sW % 8) {
+        set_error("gemm_bf16x3: bad shape M=%d N=%d K=%d lda=%d ldw=%d (K must be a multiple of %d)", M, N, K, lda, ldw, XBK);
         return MDD_ERR_ARG;
     }
-    static const int mode = getenv("MDD_GEMM") ? (!strcmp(getenv("MDD_GEMM"), "regs") ? 0 : (!strcmp(getenv("MDD_GEMM"), "glds128") ? 1 : 2)) : 2;
-    if (mode == 2 && !Csplit && batch == 1 && M >= 1024 && N >= 512) {   // large projection: LDS-DMA, 256x256 tiles
+    if (!Csplit && batch == 1 && M >= 1024 && N >= 512) {   // large projection: 256x256 tiles
         const int tn = (N + 255) / 256;
-        static const int shape = getenv("MDD_MFMA32") ? 0 : 1;   // 16x16x32 holds a higher clock on real data: 2.00 vs 2.32 ms in the model
-        static const bool ph8 = !(getenv("MDD_GEMM") && !strcmp(getenv("MDD_GEMM"), "glds256")) && !getenv("MDD_MFMA32");
-        if (ph8) hipLaunchKernelGGL(gemm_bf16x3_ph8_kernel, dim3(((M + 255) / 256) * tn), dim3(512), 2 * 4 * 256 * XROW, st, A.hi, A.lo, W.hi, W.lo, bias,
-                           C, M, N, K, lda, ldw, ldc, tn);
-        else if (shape) hipLaunchKernelGGL(gemm_bf16x3_glds256_kernel<1>, dim3(((M + 255) / 256) * tn), dim3(512), 2 * 4 * 256 * XROW, st, A.hi, A.lo, W.hi, W.lo, bias,
-                           C, M, N, K, lda, ldw, ldc, tn);
-        else hipLaunchKernelGGL(gemm_bf16x3_glds256_kernel<0>, dim3(((M + 255) / 256) * tn), dim3(512), 2 * 4 * 256 * XROW, st, A.hi, A.lo, W.hi, W.lo, bias,
-                           C, M, N, K, lda, ldw, ldc, tn);
+        const dim3 grid(((M + 255) / 256) * tn), block(512);
+        const size_t smem = 2 * 4 * 256 * XROW;
+        // MDD_GEMM=glds256: the single-barrier kernel; MDD_GEMM_DMA=M: the 8-phase kernel with the LDS-DMA issued from inside the MFMA
+        // phases (measured 5-8 % slower than from the load phases: profiles/round2_gemm_phase_stamps.txt)
+        static const int form = (getenv("MDD_GEMM") && !strcmp(getenv("MDD_GEMM"), "glds256")) ? 0 : ((getenv("MDD_GEMM_DMA") && !strcmp(getenv("MDD_GEMM_DMA"), "M")) ? 2 : 1);
+        if (form == 2) hipLaunchKernelGGL(gemm_bf16x3_ph8_kernel<true>, grid, block, smem, st, A.hi, A.lo, W.hi, W.lo, bias, C, M, N, K, lda, ldw, ldc, tn);
+        else if (form == 1) hipLaunchKernelGGL(gemm_bf16x3_ph8_kernel<false>, grid, block, smem, st, A.hi, A.lo, W.hi, W.lo, bias, C, M, N, K, lda, ldw, ldc, tn);
+        else hipLaunchKernelGGL(gemm_bf16x3_glds256_kernel, grid, block, smem, st, A.hi, A.lo, W.hi, W.lo, bias, C, M, N, K, lda, ldw, ldc, tn);
         MDD_LAUNCH_CHECK();
         return MDD_OK;
     }
-    if (mode >= 1 && K % XBK == 0) {                                     // LDS-DMA, 128x128 tiles (also batched / split output)
-        const int tm = (M + XBM - 1) / XBM, tn = (N + XBN - 1) / XBN;
-        dim3 grid(tm * tn, 1, batch), block(256);
-        if (Csplit)
-            hipLaunchKernelGGL(gemm_bf16x3_glds_kernel<1>, grid, block, 0, st, A.hi, A.lo, W.hi, W.lo, bias, (float *)nullptr, Csplit->hi, Csplit->lo,
-                               M, N, K, lda, ldw, ldc, sA, sW, sC, tn);
-        else
-            hipLaunchKernelGGL(gemm_bf16x3_glds_kernel<0>, grid, block, 0, st, A.hi, A.lo, W.hi, W.lo, bias, C, (unsigned short *)nullptr,
-                               (unsigned short *)nullptr, M, N, K, lda, ldw, ldc, sA, sW, sC, tn);
-        MDD_LAUNCH_CHECK();
-        return MDD_OK;
-    }
-    const int tiles_m = (M + XBM - 1) / XBM, tiles_n = (N + XBN - 1) / XBN;
-    dim3 grid(tiles_m * tiles_n, 1, batch), block(256);
+    const int tm = (M + XBM - 1) / XBM, tn = (N + XBN - 1) / XBN;   // 128x128 tiles (also batched / split output)
+    dim3 grid(tm * tn, 1, batch), block(256);
     if (Csplit)
-        hipLaunchKernelGGL(gemm_bf16x3_kernel<1>, grid, block, 0, st, A.hi, A.lo, W.hi, W.lo, bias, (float *)nullptr, Csplit->hi,
-                           Csplit->lo, M, N, K, lda, ldw, ldc, sA, sW, sC, tiles_n);
+        hipLaunchKernelGGL(gemm_bf16x3_glds_kernel<1>, grid, block, 0, st, A.hi, A.lo, W.hi, W.lo, bias, (float *)nullptr, Csplit->hi, Csplit->lo,
+                           M, N, K, lda, ldw, ldc, sA, sW, sC, tn);
     else
-        hipLaunchKernelGGL(gemm_bf16x3_kernel<0>, grid, block, 0, st, A.hi, A.lo, W.hi, W.lo, bias, C, (unsigned short *)nullptr,
-                           (unsigned short *)nullptr, M, N, K, lda, ldw, ldc, sA, sW, sC, tiles_n);
+        hipLaunchKernelGGL(gemm_bf16x3_glds_kernel<0>, grid, block, 0, st, A.hi, A.lo, W.hi, W.lo, bias, C, (unsigned short *)nullptr,
+                           (unsigned short *)nullptr, M, N, K, lda, ldw, ldc, sA, sW, sC, tn);
     MDD_LAUNCH_CHECK();
     return MDD_OK;
 }
 
 }  // namespace mdd
-// Diagnostic hook (not part of the product ABI): time the GEMM kernel and its ablations.
-extern "C" int mdd_diag_gemm(int M, int N, int K, int abl, int iters, float *ms_out) {
-    using namespace mdd;
-    const int pad = getenv("MDD_DIAG_PAD") ? atoi(getenv("MDD_DIAG_PAD")) : 0;   // extra elements per row (leading-dimension experiment)
-    const int LD = K + pad;
-    unsigned short *A = nullptr, *W = nullptr; float *C = nullptr;
-    MDD_HIP_CHECK(hipMalloc((void **)&A, (size_t)2 * M * LD * 2));
-    MDD_HIP_CHECK(hipMalloc((void **)&W, (size_t)2 * N * LD * 2));
-    MDD_HIP_CHECK(hipMalloc((void **)&C, (size_t)M * N * 4));
-    MDD_HIP_CHECK(hipMemset(A, 0x3c, (size_t)2 * M * LD * 2));
-    MDD_HIP_CHECK(hipMemset(W, 0x3b, (size_t)2 * N * LD * 2));
-    const int tiles_m = (M + XBM - 1) / XBM, tiles_n = (N + XBN - 1) / XBN;
-    dim3 grid(tiles_m * tiles_n, 1, 1), block(256);
-    hipEvent_t e0, e1; MDD_HIP_CHECK(hipEventCreate(&e0)); MDD_HIP_CHECK(hipEventCreate(&e1));
-    for (int it = -1; it < iters; it++) {
-        if (it == 0) MDD_HIP_CHECK(hipEventRecord(e0, nullptr));
-#define LAUNCH_ABL(X) hipLaunchKernelGGL((gemm_bf16x3_kernel<0, X>), grid, block, 0, nullptr, A, A + (size_t)M * K, W, W + (size_t)N * K, (const float *)nullptr, C, \
-                                          (unsigned short *)nullptr, (unsigned short *)nullptr, M, N, K, K, K, N, 0l, 0l, 0l, tiles_n)
-        if (abl == 9) {
-            static bool at = false; if (!at) { init_gemm_attributes(); at = true; }
-            const int t256n = (N + 255) / 256;
-            hipLaunchKernelGGL(gemm_bf16x3_glds256_kernel<0>, dim3(((M + 255) / 256) * t256n), dim3(512), 2 * 4 * 256 * XROW, nullptr, A, A + (size_t)M * LD, W, W + (size_t)N * LD,
-                               (const float *)nullptr, C, M, N, K, LD, LD, N, t256n);
-            continue;
-        }
-        if (abl == 10) {
-            static bool at = false; if (!at) { init_gemm_attributes(); at = true; }
-            const int t256n = (N + 255) / 256;
-            hipLaunchKernelGGL(gemm_bf16x3_glds256_kernel<1>, dim3(((M + 255) / 256) * t256n), dim3(512), 2 * 4 * 256 * XROW, nullptr, A, A + (size_t)M * LD, W, W + (size_t)N * LD,
-                               (const float *)nullptr, C, M, N, K, LD, LD, N, t256n);
-            continue;
-        }
-        if (abl == 8) {
-            hipLaunchKernelGGL((gemm_bf16x3_glds_kernel<0>), grid, block, 0, nullptr, A, A + (size_t)M * LD, W, W + (size_t)N * LD, (const float *)nullptr, C,
-                               (unsigned short *)nullptr, (unsigned short *)nullptr, M, N, K, LD, LD, N, 0l, 0l, 0l, tiles_n);
-            continue;
-        }
-        switch (abl) { case 0: LAUNCH_ABL(0); break; case 1: LAUNCH_ABL(1); break; case 2: LAUNCH_ABL(2); break; case 3: LAUNCH_ABL(3); break;
-                       case 6: LAUNCH_ABL(6); break; default: LAUNCH_ABL(7); }
-#undef LAUNCH_ABL
-    }
-    MDD_HIP_CHECK(hipEventRecord(e1, nullptr)); MDD_HIP_CHECK(hipEventSynchronize(e1));
-    float t = 0; MDD_HIP_CHECK(hipEventElapsedTime(&t, e0, e1)); *ms_out = t / iters;
-    (void)hipFree(A); (void)hipFree(W); (void)hipFree(C); (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-    return MDD_OK;
-}
 namespace mdd {
 __global__ void diag_fill_kernel(unsigned short *p, size_t n, unsigned seed) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
@@ -693,12 +469,13 @@ __global__ void diag_diff_kernel(const unsigned *a, const unsigned *b, size_t n,
 }
 }  // namespace mdd
 
-// Race screen for the 8-phase kernel (not part of the ABI; tests/test_gpu_parity.py): the same pseudo-random split
-// operands through the single-barrier kernel once and through the 8-phase kernel `reps` times; returns the number of
-// C words that ever differed (both kernels perform the same arithmetic per element, so it must be 0).
-extern "C" int mdd_diag_gemm_ph8(int M, int N, int K, int reps, unsigned seed, unsigned *mismatches_out) {
+// Race screen for the 8-phase kernel (tests/test_gpu_parity.py): the same pseudo-random split operands through the single-barrier
+// kernel once and through BOTH forms of the 8-phase kernel (LDS-DMA issued from the load phases / from the MFMA phases) `reps` times
+// each; returns the number of C words that ever differed (all perform the same arithmetic per element, so it must be 0).
+// ms_out (nullable): [single-barrier, 8-phase DMA-in-L, 8-phase DMA-in-M] mean kernel time over the repetitions, HIP events.
+extern "C" int mdd_diag_gemm_ph8(int M, int N, int K, int reps, unsigned seed, unsigned *mismatches_out, float *ms_out) {
     using namespace mdd;
-    if (M <= 0 || N <= 0 || K < XBK || K % XBK || !mismatches_out) { set_error("mdd_diag_gemm_ph8: bad shape"); return MDD_ERR_ARG; }
+    if (M <= 0 || N <= 0 || K < XBK || K % XBK || !mismatches_out || reps < 1) { set_error("mdd_diag_gemm_ph8: bad shape"); return MDD_ERR_ARG; }
     static bool at = false; if (!at) { if (int rc = init_gemm_attributes()) return rc; at = true; }
     unsigned short *A = nullptr, *W = nullptr; float *C1 = nullptr, *C2 = nullptr; unsigned *cnt = nullptr;
     MDD_HIP_CHECK(hipMalloc((void **)&A, (size_t)2 * M * K * 2));
@@ -707,21 +484,55 @@ extern "C" int mdd_diag_gemm_ph8(int M, int N, int K, int reps, unsigned seed, u
     MDD_HIP_CHECK(hipMalloc((void **)&C2, (size_t)M * N * 4));
     MDD_HIP_CHECK(hipMalloc((void **)&cnt, 4));
     MDD_HIP_CHECK(hipMemset(cnt, 0, 4));
+    hipEvent_t e0, e1; MDD_HIP_CHECK(hipEventCreate(&e0)); MDD_HIP_CHECK(hipEventCreate(&e1));
     hipLaunchKernelGGL(diag_fill_kernel, dim3(1024), dim3(256), 0, nullptr, A, (size_t)2 * M * K, seed);
     hipLaunchKernelGGL(diag_fill_kernel, dim3(1024), dim3(256), 0, nullptr, W, (size_t)2 * N * K, seed * 7919u + 13u);
     const int tn = (N + 255) / 256;
     const dim3 grid(((M + 255) / 256) * tn), block(512);
-    hipLaunchKernelGGL(gemm_bf16x3_glds256_kernel<1>, grid, block, 2 * 4 * 256 * XROW, nullptr, A, A + (size_t)M * K, W, W + (size_t)N * K,
-                       (const float *)nullptr, C1, M, N, K, K, K, N, tn);
-    for (int r = 0; r < reps; r++) {
-        MDD_HIP_CHECK(hipMemsetAsync(C2, 0xff, (size_t)M * N * 4, nullptr));
-        hipLaunchKernelGGL(gemm_bf16x3_ph8_kernel, grid, block, 2 * 4 * 256 * XROW, nullptr, A, A + (size_t)M * K, W, W + (size_t)N * K,
-                           (const float *)nullptr, C2, M, N, K, K, K, N, tn);
-        hipLaunchKernelGGL(diag_diff_kernel, dim3(1024), dim3(256), 0, nullptr, reinterpret_cast<const unsigned *>(C1),
-                           reinterpret_cast<const unsigned *>(C2), (size_t)M * N, cnt);
+    float ms[3] = {0.f, 0.f, 0.f};
+    for (int form = 0; form < 3; form++) {
+        for (int r = 0; r < reps; r++) {
+            float *dst = form == 0 ? C1 : C2;
+            if (form) MDD_HIP_CHECK(hipMemsetAsync(C2, 0xff, (size_t)M * N * 4, nullptr));
+            MDD_HIP_CHECK(hipEventRecord(e0, nullptr));
+            if (form == 0) hipLaunchKernelGGL(gemm_bf16x3_glds256_kernel, grid, block, 2 * 4 * 256 * XROW, nullptr, A, A + (size_t)M * K, W, W + (size_t)N * K,
+                                              (const float *)nullptr, dst, M, N, K, K, K, N, tn);
+            else if (form == 1) hipLaunchKernelGGL(gemm_bf16x3_ph8_kernel<false>, grid, block, 2 * 4 * 256 * XROW, nullptr, A, A + (size_t)M * K, W, W + (size_t)N * K,
+                                                   (const float *)nullptr, dst, M, N, K, K, K, N, tn);
+            else hipLaunchKernelGGL(gemm_bf16x3_ph8_kernel<true>, grid, block, 2 * 4 * 256 * XROW, nullptr, A, A + (size_t)M * K, W, W + (size_t)N * K,
+                                    (const float *)nullptr, dst, M, N, K, K, K, N, tn);
+            MDD_HIP_CHECK(hipEventRecord(e1, nullptr));
+            MDD_HIP_CHECK(hipEventSynchronize(e1));
+            float t = 0.f; MDD_HIP_CHECK(hipEventElapsedTime(&t, e0, e1));
+            if (r > 0 || reps == 1) ms[form] += t;
+            if (form) hipLaunchKernelGGL(diag_diff_kernel, dim3(1024), dim3(256), 0, nullptr, reinterpret_cast<const unsigned *>(C1),
+                                         reinterpret_cast<const unsigned *>(C2), (size_t)M * N, cnt);
+        }
+        ms[form] /= (float)(reps > 1 ? reps - 1 : 1);
     }
     MDD_HIP_CHECK(hipMemcpy(mismatches_out, cnt, 4, hipMemcpyDeviceToHost));
-    hipFree(A); hipFree(W); hipFree(C1); hipFree(C2); hipFree(cnt);
+    if (ms_out) { ms_out[0] = ms[0]; ms_out[1] = ms[1]; ms_out[2] = ms[2]; }
+    if (ms_out && getenv("MDD_GEMM_STAMP")) {   // phase stamps of both forms: ms_out[3..6] (DMA in L) and [7..10] (DMA in M), mean cycles per K-tile and wave
+        long long *sd = nullptr;
+        MDD_HIP_CHECK(hipMalloc((void **)&sd, sizeof(long long) * 256 * 8 * 4));
+        std::vector<long long> hs(256 * 8 * 4);
+        for (int form = 0; form < 2; form++) {
+            MDD_HIP_CHECK(hipMemset(sd, 0, sizeof(long long) * 256 * 8 * 4));
+            if (form == 0) hipLaunchKernelGGL((gemm_bf16x3_ph8_kernel<false, true>), grid, block, 2 * 4 * 256 * XROW, nullptr, A, A + (size_t)M * K, W, W + (size_t)N * K,
+                                              (const float *)nullptr, C2, M, N, K, K, K, N, tn, sd);
+            else hipLaunchKernelGGL((gemm_bf16x3_ph8_kernel<true, true>), grid, block, 2 * 4 * 256 * XROW, nullptr, A, A + (size_t)M * K, W, W + (size_t)N * K,
+                                    (const float *)nullptr, C2, M, N, K, K, K, N, tn, sd);
+            MDD_HIP_CHECK(hipMemcpy(hs.data(), sd, sizeof(long long) * 256 * 8 * 4, hipMemcpyDeviceToHost));
+            const int nwg = std::min(256, (int)grid.x);
+            for (int i = 0; i < 4; i++) {
+                double tot = 0;
+                for (int w = 0; w < nwg * 8; w++) tot += (double)hs[(size_t)w * 4 + i];
+                ms_out[3 + form * 4 + i] = (float)(tot / (nwg * 8) / (K / XBK));
+            }
+        }
+        (void)hipFree(sd);
+    }
+    (void)hipFree(A); (void)hipFree(W); (void)hipFree(C1); (void)hipFree(C2); (void)hipFree(cnt); (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     MDD_LAUNCH_CHECK();
     return MDD_OK;
 }

@@ -29,7 +29,9 @@ __device__ __forceinline__ float fast_sigmoid(float v) { return __builtin_amdgcn
 __device__ __forceinline__ float fast_tanh(float v) { return 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + __expf(2.f * v)); }
 
 // ---- generic variant (any H % 4 == 0; row-major Whh', h and c): used for small test geometries
-template <bool VEC>
+// VEC: 0 scalar k loop (any H % 4 == 0), 1 float4 k loop (H % 16 == 0), N > 1: a lane's quarter of the contraction is exactly N
+// float4 steps (24 at H = 384, 16 at H = 256) and all of its loads are issued before the first MFMA (one L2 round trip per step).
+template <int VEC>
 __global__ __launch_bounds__(256) void lstm_step_kernel(LstmStepArgs a, int s) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int ut = blockIdx.x, d = blockIdx.y;
@@ -46,7 +48,19 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(LstmStepArgs a, int s) {
     if (s > 0) {
         const float *wp = a.whh + ((size_t)d * 4 * H + ut * 16 + li) * H + kq * KQ;  // A[row li][k quarter kq]
         const float *hp = hprev + (size_t)bc * H + kq * KQ;                            // B[k quarter kq][col li]
-        if (VEC) {
+        if (VEC > 1) {
+            float4 w4[VEC > 1 ? VEC : 1], h4[VEC > 1 ? VEC : 1];
+#pragma unroll
+            for (int n = 0; n < VEC; n++) { w4[n] = *reinterpret_cast<const float4 *>(wp + 4 * n); h4[n] = *reinterpret_cast<const float4 *>(hp + 4 * n); }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int n = 0; n < VEC; n++) {    // same accumulation order as the float4 loop below: one chain, x y z w per step
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w4[n].x, h4[n].x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w4[n].y, h4[n].y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w4[n].z, h4[n].z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w4[n].w, h4[n].w, acc, 0, 0, 0);
+            }
+        } else if (VEC) {
 #pragma unroll 8
             for (int k = 0; k < KQ; k += 4) {
                 float4 w4 = *reinterpret_cast<const float4 *>(wp + k);
@@ -301,27 +315,16 @@ int init_lstm_attributes() {
     return MDD_OK;
 }
 
-// ---- persistent layer kernel: the whole recurrence of one BiLSTM layer in ONE launch.
-// The per-step launches above re-read W_hh (4.7 MB) from L2 every step; measured, a CU ingests only ~50-100 GB/s
-// from L2, so at fused batch sizes the step is bound by that re-read.  Here 256 workgroups (one per CU) are
-// resident for the whole layer:
-//   * 16 teams = 2 directions x 8 batch groups; a team = 16 workgroups, each owning 4H/16 gate rows (H/16 units);
-//   * a wave owns one 16-row tile of W_hh' and keeps its bf16 hi/lo MFMA fragments IN REGISTERS for all T steps
-//     (H/32 k-steps x 2 planes x 4 VGPRs = 96 VGPRs at H=384); c never leaves registers either;
-//   * per step only h moves: each workgroup publishes its [BG x H/16] slice of h_t as bf16 hi/lo (8-byte
-//     write-through granules), bumps the team counter, waits for the 16 arrivals of the team, pulls the team's
-//     [BG x H] panel (49 KB at BG=32) into LDS and runs the bf16x3 MFMAs against its resident fragments.
-// Hand-off = MI355X guide, Guideline 16 form R1 with sc1 loads in place of the acquire: payload stored with
-// agent-scope relaxed atomics (sc1, write-through), every storing wave drains vmcnt, workgroup barrier, ONE lane
-// adds to the team counter; consumers poll that counter relaxed from one lane, barrier, then read the payload with
-// agent-scope relaxed atomic loads (sc1: bypass the CU's L1).  Placement (teams share an XCD under round-robin
-// dispatch) is a speed choice only.  Every spin is bounded (wall-clock timeout -> abort flag + error code), so a
-// launch that is not fully resident ends with an error instead of hanging.
+// ---- persistent layer kernel: the whole recurrence of one BiLSTM layer in ONE launch (lstm_layer_granule_kernel below).
+// The per-step launches above re-read W_hh (4.7 MB) from L2 every step; measured, a CU ingests only ~50-100 GB/s from L2, so at
+// fused batch sizes the step is bound by that re-read.  The persistent form keeps every workgroup's W_hh rows in registers for
+// the whole layer and moves only h between the workgroups of a team.  (An earlier form of it -- 16-workgroup teams around a
+// per-team arrival counter -- was superseded by the data-tagged hand-off and is no longer built.)
 struct PersistArgs {
     const float *gx;                 // [T][B][2][4H] permuted gate columns
     SplitPtr whh;                    // Whh' [2][4H][H] row-major hi/lo
-    unsigned short *hx;              // [2 parity][16 teams][2 planes][BG][H]
-    unsigned int *sync;              // [16] team counters, [16] abort flag  (zeroed before every launch)
+    unsigned short *hx;              // [2 parity][32 teams][tiles][H/4 chunk columns][16 rows] x 16 B: tagged chunks of the state in flight
+    unsigned int *sync;              // [16] unused, [16] abort flag  (zeroed before every launch)
     int *err_flag;
     float *out, *out_raw;
     SplitPtr out_split;
@@ -334,171 +337,9 @@ struct PersistArgs {
 
 typedef unsigned long long u64;
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ u64 ld_agent(const u64 *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void st_agent(u64 *p, u64 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
-template <int H, int NBT>
-__global__ __launch_bounds__(H / 64 * 64, 1) void lstm_layer_persistent_kernel(PersistArgs a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int NTH = H / 64 * 64, KS = H / 32, ROWB = H * 2 + 16, RM = 4 * H / 16;
-    const int BG = a.BG;
-    unsigned char *Ph = smem, *Pl = smem + (size_t)BG * ROWB;      // h panel, hi / lo planes, padded rows
-    __shared__ int s_fail;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int li = lane & 15, kq = lane >> 4;
-    const int w = blockIdx.x, xl = w & 7, j = w >> 3;
-    const int team = xl * 2 + (j >> 4), member = j & 15;           // the 16 members of a team share blockIdx%8 (one XCD under round-robin)
-    const int d = team >> 3, g = team & 7;
-    const int r0 = member * RM + wave * 16;                        // first gate row of this wave's tile
-    const int u = (r0 >> 2) + kq;                                  // hidden unit of this lane (D row = 4*kq + gate)
-    const int B = a.B, T = a.T;
-    if (tid == 0) s_fail = 0;
-
-    // resident A fragments: lane (row li, k-slice kq) of tile rows r0..r0+15
-    bf16x8 ah[KS], al[KS];
-    {
-        const unsigned short *wh = a.whh.hi + ((size_t)d * 4 * H + r0 + li) * H + kq * 8;
-        const unsigned short *wl = a.whh.lo + ((size_t)d * 4 * H + r0 + li) * H + kq * 8;
-#pragma unroll
-        for (int ks = 0; ks < KS; ks++) {
-            ah[ks] = *reinterpret_cast<const bf16x8 *>(wh + ks * 32);
-            al[ks] = *reinterpret_cast<const bf16x8 *>(wl + ks * 32);
-        }
-    }
-    const float osc = a.oscale ? a.oscale[d * H + u] : 1.f, osh = a.oscale ? a.oshift[d * H + u] : 0.f;   // next layer's folded BatchNorm
-    float cst[NBT];
-#pragma unroll
-    for (int bt = 0; bt < NBT; bt++) cst[bt] = 0.f;
-    const size_t plane = (size_t)BG * H;                           // elements per (team, plane)
-    unsigned int *cnt = a.sync + team, *abortf = a.sync + 16;
-    __syncthreads();
-
-    long long ph[6] = {0, 0, 0, 0, 0, 0}, tst = a.dbg ? (long long)__builtin_readcyclecounter() : 0;
+// diagnostic phase stamps (MDD_LSTM_DBG): cycle sums per phase of the step, read by tools/lstm_stamps.py
 #define PSTAMP(i) do { if (a.dbg) { long long n_ = __builtin_readcyclecounter(); ph[i] += n_ - tst; tst = n_; } } while (0)
-    for (int s = 0; s < T; s++) {
-        const int t = d ? (T - 1 - s) : s;
-        // gx of this step does not depend on h: issue it before the wait
-        float4 g4[NBT];
-#pragma unroll
-        for (int bt = 0; bt < NBT; bt++) {
-            const int lb = bt * 16 + li, b = g * a.BGr + lb;
-            const bool valid = lb < a.BGr && b < B;
-            g4[bt] = valid ? *reinterpret_cast<const float4 *>(a.gx + (((size_t)t * B + b) * 2 + d) * 4 * H + u * 4)
-                           : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-        f32x4 acc[NBT];
-#pragma unroll
-        for (int bt = 0; bt < NBT; bt++) acc[bt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (s > 0) {
-            if (tid == 0) {   // wait until every member of the team has published h_{s-1}
-                const unsigned int target = 16u * (unsigned)s;
-                const long long t0 = wall_clock64();
-                int fail = 0;
-                while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-                    __builtin_amdgcn_s_sleep(1);
-                    if (__hip_atomic_load(abortf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 ||
-                        wall_clock64() - t0 > 200000000ll) { fail = 1; break; }       // 2 s at 100 MHz
-                }
-                if (fail) {
-                    __hip_atomic_store(abortf, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    atomicExch(a.err_flag, 2);
-                    s_fail = 1;
-                }
-            }
-            __syncthreads();
-            PSTAMP(0);
-            if (s_fail) return;
-            // pull the team's panel (parity (s-1)&1) into LDS: 16-byte sc1 buffer loads (bypass this CU's L1, served by
-            // L2 / fabric), every load of the panel in flight before the first LDS write
-            {
-                const unsigned short *srcp = a.hx + ((size_t)(((s - 1) & 1) * 16 + team) * 2) * plane;
-                const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short *>(srcp), 0,
-                                                                                      (int)(2 * plane * sizeof(unsigned short)), 0x00020000);
-                constexpr int NLD = (2 * NBT * 16 * H / 8 + NTH - 1) / NTH;     // 16-byte chunks per thread
-                const int n16 = (int)(2 * plane / 8);
-                u32x4 pv[NLD];
-#pragma unroll
-                for (int i = 0; i < NLD; i++) {
-                    const int q = tid + NTH * i;
-                    pv[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (q < n16 ? q : n16 - 1) * 16, 0, 16 /* sc1 */);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int i = 0; i < NLD; i++) {
-                    const int q = tid + NTH * i;
-                    if (q < n16) {
-                        const int pl = q >= n16 / 2, qq = pl ? q - n16 / 2 : q;
-                        const int row = qq / (H / 8), c16 = qq - row * (H / 8);
-                        *reinterpret_cast<u32x4 *>((pl ? Pl : Ph) + row * ROWB + c16 * 16) = pv[i];
-                    }
-                }
-            }
-            __syncthreads();
-            PSTAMP(1);
-#pragma unroll
-            for (int ks = 0; ks < KS; ks++) {
-#pragma unroll
-                for (int bt = 0; bt < NBT; bt++) {
-                    const bf16x8 bh = *reinterpret_cast<const bf16x8 *>(Ph + (bt * 16 + li) * ROWB + ks * 64 + kq * 16);
-                    const bf16x8 bl = *reinterpret_cast<const bf16x8 *>(Pl + (bt * 16 + li) * ROWB + ks * 64 + kq * 16);
-                    acc[bt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[ks], bl, acc[bt], 0, 0, 0);
-                    acc[bt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[ks], bh, acc[bt], 0, 0, 0);
-                    acc[bt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[ks], bh, acc[bt], 0, 0, 0);
-                }
-            }
-        }
-        PSTAMP(2);
-        // cell update + publish h_s
-        u64 *dst = reinterpret_cast<u64 *>(a.hx + ((size_t)((s & 1) * 16 + team) * 2) * plane);
-        float hcur[NBT];
-#pragma unroll
-        for (int bt = 0; bt < NBT; bt++) {
-            const int lb = bt * 16 + li, b = g * a.BGr + lb;
-            const bool valid = lb < a.BGr && b < B;
-            const float ig = fast_sigmoid(acc[bt][0] + g4[bt].x), fg = fast_sigmoid(acc[bt][1] + g4[bt].y);
-            const float cg = fast_tanh(acc[bt][2] + g4[bt].z), og = fast_sigmoid(acc[bt][3] + g4[bt].w);
-            const float cn = fg * cst[bt] + ig * cg;
-            const float hn = valid ? og * fast_tanh(cn) : 0.f;
-            cst[bt] = cn;
-            hcur[bt] = hn;
-            // gather the 4 units of this row tile (lanes li, li+16, li+32, li+48) into one 8-byte granule per plane
-            const unsigned int pk = split_h(hn);
-            const unsigned int p1 = __shfl(pk, li + 16), p2 = __shfl(pk, li + 32), p3 = __shfl(pk, li + 48);
-            if (kq == 0) {
-                const u64 hi4 = (u64)(pk & 0xffffu) | ((u64)(p1 & 0xffffu) << 16) | ((u64)(p2 & 0xffffu) << 32) | ((u64)(p3 & 0xffffu) << 48);
-                const u64 lo4 = (u64)(pk >> 16) | ((u64)(p1 >> 16) << 16) | ((u64)(p2 >> 16) << 32) | ((u64)(p3 >> 16) << 48);
-                const size_t e = ((size_t)lb * H + (r0 >> 2)) / 4;  // granule index inside a plane: units r0/4 .. r0/4+3 of row lb
-                st_agent(dst + e, hi4);
-                st_agent(dst + plane / 4 + e, lo4);
-            }
-        }
-        PSTAMP(3);
-        if (s + 1 < T) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every storing wave drains its write-through stores
-            __syncthreads();
-            if (tid == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        // layer outputs: plain stores, off the hand-off's critical path (they overlap the wait for the team)
-#pragma unroll
-        for (int bt = 0; bt < NBT; bt++) {
-            const int lb = bt * 16 + li, b = g * a.BGr + lb;
-            if (lb < a.BGr && b < B) {
-                const float hn = hcur[bt];
-                const size_t oi = ((size_t)t * B + b) * 2 * H + d * H + u;
-                if (a.out_raw) a.out_raw[oi] = hn;
-                const float ov = a.oscale ? hn * osc + osh : hn;
-                if (a.out && a.out != a.out_raw) a.out[oi] = ov;
-                if (a.out_split.hi) {
-                    __bf16 ob = (__bf16)ov, ol = (__bf16)(ov - (float)ob);
-                    a.out_split.hi[oi] = *reinterpret_cast<unsigned short *>(&ob);
-                    a.out_split.lo[oi] = *reinterpret_cast<unsigned short *>(&ol);
-                }
-            }
-        }
-        PSTAMP(4);
-    }
-    if (a.dbg && tid == 0) for (int i = 0; i < 6; i++) a.dbg[blockIdx.x * 6 + i] = ph[i];
-}
 
 // acc += A.B with A taken straight from an accumulation-file register (half of the resident weight fragments live
 // there: the compiler would otherwise copy each one to a VGPR with four v_accvgpr_read per MFMA, on every step)
@@ -968,53 +809,14 @@ int persistent_grid_fits(int n_cu) {
     return per_cu >= 1 ? 1 : 0;
 }
 
-template <int H, int NBT>
-static int launch_persistent_t(const PersistArgs &a, hipStream_t st) {
-    constexpr int ROWB = H * 2 + 16;
-    const size_t smem = (size_t)2 * a.BG * ROWB;
-    MDD_HIP_CHECK(hipMemsetAsync(a.sync, 0, 32 * sizeof(unsigned int), st));
-    hipLaunchKernelGGL((lstm_layer_persistent_kernel<H, NBT>), dim3(kPersistGrid), dim3(H / 64 * 64), smem, st, a);
-    MDD_LAUNCH_CHECK();
-    return MDD_OK;
-}
-
-int persistent_bg(int B) { const int r = (B + 7) / 8; return r <= 16 ? 16 : (r <= 32 ? 32 : 64); }   // rows per batch group, padded
-
-int launch_lstm_layer_persistent(const LstmStepArgs &s, unsigned short *hx, unsigned int *sync, int *err_flag, hipStream_t st) {
-    PersistArgs a;
-    a.gx = s.gx; a.whh = s.whh_split; a.hx = hx; a.sync = sync; a.err_flag = err_flag;
-    a.out = s.out; a.out_raw = s.out_raw; a.out_split = s.out_split; a.oscale = s.oscale; a.oshift = s.oshift;
-    a.T = s.T; a.B = s.B; a.BGr = (s.B + 7) / 8; a.BG = persistent_bg(s.B); a.seqlen = nullptr;
-    if (s.seqlen) { set_error("persistent lstm (counter form): fused batches of different lengths need the granule form"); return MDD_ERR_ARG; }
-    a.dbg = (getenv("MDD_LSTM_DBG") && s.T > 100) ? reinterpret_cast<long long *>(hx + (size_t)2 * 16 * 2 * a.BG * s.H) : nullptr;
-    a.early = 0;
-    const int nbt = a.BG / 16;
-    if (s.H == 384) {
-        if (nbt == 1) return launch_persistent_t<384, 1>(a, st);
-        if (nbt == 2) return launch_persistent_t<384, 2>(a, st);
-        if (nbt == 4) return launch_persistent_t<384, 4>(a, st);
-    } else if (s.H == 256) {
-        if (nbt == 1) return launch_persistent_t<256, 1>(a, st);
-        if (nbt == 2) return launch_persistent_t<256, 2>(a, st);
-        if (nbt == 4) return launch_persistent_t<256, 4>(a, st);
-    }
-    set_error("persistent lstm: unsupported shape H=%d B=%d", s.H, s.B);
-    return MDD_ERR_ARG;
-}
-
-int init_persistent_attributes() {
-#define PATTR(H, N) MDD_HIP_CHECK(hipFuncSetAttribute((const void *)lstm_layer_persistent_kernel<H, N>, hipFuncAttributeMaxDynamicSharedMemorySize, 112 * 1024))
-    PATTR(384, 1); PATTR(384, 2); PATTR(384, 4); PATTR(256, 1); PATTR(256, 2); PATTR(256, 4);
-#undef PATTR
-    return MDD_OK;
-}
-
 int launch_lstm_layer_train(const LstmStepArgs &a, hipStream_t st) {
     if (a.H % 4 != 0 || a.T <= 0 || a.B <= 0 || a.packed || a.hsplit) { set_error("lstm (train): bad arguments T=%d B=%d H=%d", a.T, a.B, a.H); return MDD_ERR_ARG; }
     dim3 grid(a.H / 4, 2, (a.B + 63) / 64), block(256);
     for (int s = 0; s < a.T; s++) {
-        if (a.H % 16 == 0) hipLaunchKernelGGL(lstm_step_kernel<true>, grid, block, 0, st, a, s);
-        else hipLaunchKernelGGL(lstm_step_kernel<false>, grid, block, 0, st, a, s);
+        if (a.H == 384) hipLaunchKernelGGL(lstm_step_kernel<24>, grid, block, 0, st, a, s);
+        else if (a.H == 256) hipLaunchKernelGGL(lstm_step_kernel<16>, grid, block, 0, st, a, s);
+        else if (a.H % 16 == 0) hipLaunchKernelGGL(lstm_step_kernel<1>, grid, block, 0, st, a, s);
+        else hipLaunchKernelGGL(lstm_step_kernel<0>, grid, block, 0, st, a, s);
     }
     MDD_LAUNCH_CHECK();
     return MDD_OK;
@@ -1034,7 +836,7 @@ int launch_lstm_layer(const LstmStepArgs &a, hipStream_t st) {
         if (a.packed && a.H == 384) hipLaunchKernelGGL(lstm_step_packed_kernel<24>, grid, block, 0, st, a, s);
         else if (a.packed && a.H == 256) hipLaunchKernelGGL(lstm_step_packed_kernel<16>, grid, block, 0, st, a, s);
         else if (a.packed) { set_error("lstm: packed layout built for H in {256,384}"); return MDD_ERR_ARG; }
-        else hipLaunchKernelGGL(lstm_step_kernel<false>, grid, block, 0, st, a, s);
+        else hipLaunchKernelGGL(lstm_step_kernel<0>, grid, block, 0, st, a, s);
     }
     MDD_LAUNCH_CHECK();
     return MDD_OK;

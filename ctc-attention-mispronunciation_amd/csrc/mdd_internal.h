@@ -91,15 +91,11 @@ int launch_attn_tail(const float *S, int Lp, const float *X, const float *V, con
 int init_kernel_attributes();
 int init_ctc_attributes();
 int init_lstm_attributes();
-int init_persistent_attributes();
-// One launch for the whole layer (256 co-resident workgroups, team-synchronised; see lstm.hip).  hx: exchange buffer
-// of 2*16*2*persistent_bg(B)*H ushorts, sync: 32 uints.  Requires B <= 512, H in {256, 384}, >= 256 CUs.
-int persistent_bg(int B);
+// One launch for the whole layer (256 co-resident workgroups in 8-workgroup teams, data-tagged hand-off; see lstm.hip).
 int granule_bg(int B);
 int init_granule_attributes();
 int persistent_grid_fits(int n_cu);   // 1 when all 256 workgroups of a persistent layer launch can be resident at once
 // data-tagged variant (8-workgroup teams, no counter): hx = 2*32*granule_bg(B)*H u64 granules (+ stamps), sync: 32 uints
 int launch_lstm_layer_granule(const LstmStepArgs &s, unsigned short *hx, unsigned int *sync, int *err_flag, hipStream_t st);
-int launch_lstm_layer_persistent(const LstmStepArgs &s, unsigned short *hx, unsigned int *sync, int *err_flag, hipStream_t st);
 
 }  // namespace mdd

@@ -490,8 +490,10 @@ int launch_transpose_whh(const float *w, float *wt, int H, hipStream_t st) {
 // The contraction over n = 4H is split over the four waves of the workgroup (one quarter each, v_mfma_f32_16x16x4_f32 with the
 // units on the MFMA row axis) and combined through LDS; the launch boundary is the step-to-step dependency.
 typedef float f32x4v __attribute__((ext_vector_type(4)));
-template <bool VEC>
-__global__ __launch_bounds__(256) void lstm_bwd_step_kernel(LstmBwdArgs a, int s) {
+// NQ4 > 0: H is a compile-time multiple of 16 and a lane's share of the contraction is NQ4 float4 steps (24 at H = 384, 16 at
+// H = 256): ALL of its loads are issued before the first MFMA, so a step pays one L2 round trip instead of one per unrolled group.
+template <int NQ4>
+__global__ __launch_bounds__(256, 1) void lstm_bwd_step_kernel(LstmBwdArgs a, int s) {
     __shared__ float red[4][16 * 16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int kt = blockIdx.x, d = blockIdx.y, b0 = blockIdx.z * 16;
@@ -506,15 +508,21 @@ __global__ __launch_bounds__(256) void lstm_bwd_step_kernel(LstmBwdArgs a, int s
         const int bb = min(b0 + li, B - 1);
         const float *wp = a.whhT + ((size_t)d * H + min(kt * 16 + li, H - 1)) * G + n0;               // A[row = unit li][n]
         const float *gp = a.dg + (((size_t)tprev * B + bb) * 2 + d) * G + n0;                        // B[n][col = batch li]
-        if (VEC) {
-#pragma unroll 4
-            for (int n = 0; n < nq; n += 4) {
-                const float4 w4 = *reinterpret_cast<const float4 *>(wp + n), g4 = *reinterpret_cast<const float4 *>(gp + n);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w4.x, g4.x, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w4.y, g4.y, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w4.z, g4.z, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w4.w, g4.w, acc, 0, 0, 0);
+        if (NQ4 > 0) {
+            float4 w4[NQ4 > 0 ? NQ4 : 1], g4[NQ4 > 0 ? NQ4 : 1];
+#pragma unroll
+            for (int n = 0; n < NQ4; n++) { w4[n] = *reinterpret_cast<const float4 *>(wp + 4 * n); g4[n] = *reinterpret_cast<const float4 *>(gp + 4 * n); }
+            __builtin_amdgcn_sched_barrier(0);
+            f32x4v a1 = acc, a2 = acc, a3 = acc;           // four chains: the dependent-issue latency of the fp32 MFMA exceeds its issue time
+#pragma unroll
+            for (int n = 0; n < NQ4; n++) {
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w4[n].x, g4[n].x, acc, 0, 0, 0);
+                a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w4[n].y, g4[n].y, a1, 0, 0, 0);
+                a2 = __builtin_amdgcn_mfma_f32_16x16x4f32(w4[n].z, g4[n].z, a2, 0, 0, 0);
+                a3 = __builtin_amdgcn_mfma_f32_16x16x4f32(w4[n].w, g4[n].w, a3, 0, 0, 0);
             }
+#pragma unroll
+            for (int r = 0; r < 4; r++) acc[r] = (acc[r] + a1[r]) + (a2[r] + a3[r]);
         } else {
             for (int n = 0; n < nq; n++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wp[n], gp[n], acc, 0, 0, 0);
         }
@@ -548,10 +556,10 @@ __global__ __launch_bounds__(256) void lstm_bwd_step_kernel(LstmBwdArgs a, int s
 int launch_lstm_bwd(const LstmBwdArgs &a, hipStream_t st) {
     if (a.H % 16 && a.H % 4) { set_error("lstm backward: H must be a multiple of 4"); return MDD_ERR_ARG; }
     dim3 grid((a.H + 15) / 16, 2, (a.B + 15) / 16), block(256);
-    const bool vec = (a.H % 16) == 0;      // quarters of 4H/16 floats, float4 steps
     for (int s = 0; s < a.T; s++) {
-        if (vec) hipLaunchKernelGGL(lstm_bwd_step_kernel<true>, grid, block, 0, st, a, s);
-        else hipLaunchKernelGGL(lstm_bwd_step_kernel<false>, grid, block, 0, st, a, s);
+        if (a.H == 384) hipLaunchKernelGGL(lstm_bwd_step_kernel<24>, grid, block, 0, st, a, s);
+        else if (a.H == 256) hipLaunchKernelGGL(lstm_bwd_step_kernel<16>, grid, block, 0, st, a, s);
+        else hipLaunchKernelGGL(lstm_bwd_step_kernel<0>, grid, block, 0, st, a, s);
     }
     MDD_LAUNCH_CHECK();
     return MDD_OK;

@@ -212,13 +212,11 @@ int mdd_train_sync(mdd_train_ws *w, void *stream);
 int mdd_adam_step(float *const *params, float *const *grads, float *const *exp_avg, float *const *exp_avg_sq, const int64_t *numel, int32_t n,
                   int32_t step, float lr, float beta1, float beta2, float eps, float weight_decay, void *stream);
 
-/* ---- Diagnostics (test and measurement aids; no reference counterpart).
- * mdd_diag_gemm: time one launch form of the split-bf16 projection GEMM on constant operands (abl selects the form;
- * tools/gemm_*.py).  mdd_diag_gemm_ph8: race screen of the 8-phase GEMM -- the same pseudo-random operands through the
- * single-barrier kernel once and the 8-phase kernel `reps` times; *mismatches_out = C words that ever differed (must be 0;
- * tests/test_gpu_parity.py::test_gemm_8phase_race_screen). */
-int mdd_diag_gemm(int M, int N, int K, int abl, int iters, float *ms_out);
-int mdd_diag_gemm_ph8(int M, int N, int K, int reps, unsigned seed, unsigned *mismatches_out);
+/* ---- Diagnostics (test and measurement aid; no reference counterpart).
+ * mdd_diag_gemm_ph8: race screen of the 8-phase projection GEMM -- the same pseudo-random operands through the single-barrier
+ * kernel once and both forms of the 8-phase kernel `reps` times; *mismatches_out = C words that ever differed (must be 0;
+ * tests/test_gpu_parity.py::test_gemm_8phase_race_screen).  ms_out (nullable, 3 floats): mean kernel time of the three forms. */
+int mdd_diag_gemm_ph8(int M, int N, int K, int reps, unsigned seed, unsigned *mismatches_out, float *ms_out);
 
 #ifdef __cplusplus
 }
