@@ -239,7 +239,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16x3_glds256_kernel(const unsig
 // Hazards: a half-tile issued in phase p is waited for at the end of L(p+2) by every wave, read in L(p+3) -- for the
 // late group that is after one more barrier than the early group's wait, as the stagger requires -- and its buffer is
 // refilled eight phases later.
-template <bool DMA_IN_M, bool STAMP = false>
+template <bool DMA_IN_M, bool STAMP = false, bool WFIRST = true>
 __global__ __launch_bounds__(512, 2) void gemm_bf16x3_ph8_kernel(const unsigned short *__restrict__ Ah, const unsigned short *__restrict__ Al,
                                                                  const unsigned short *__restrict__ Wh, const unsigned short *__restrict__ Wl,
                                                                  const float *__restrict__ bias, float *__restrict__ C, int M, int N, int K,
@@ -304,10 +304,11 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16x3_ph8_kernel(const unsigned 
             fah[i] = x3_frag(st, (a_) * 128 + wr * 64 + i * 16 + l16, kq16); fal[i] = x3_frag(st + PL, (a_) * 128 + wr * 64 + i * 16 + l16, kq16); }
 #define PH8_LOAD_W(b_) _Pragma("unroll") for (int j = 0; j < 2; j++) { \
             fwh[b_][j] = x3_frag(st + 2 * PL, (b_) * 128 + wc * 32 + j * 16 + l16, kq16); fwl[b_][j] = x3_frag(st + 3 * PL, (b_) * 128 + wc * 32 + j * 16 + l16, kq16); }
+#define PH8_MM(x_, y_, c_) (WFIRST ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(x_, y_, c_, 0, 0, 0) : __builtin_amdgcn_mfma_f32_16x16x32_bf16(y_, x_, c_, 0, 0, 0))
 #define PH8_MFMA(a_, b_) _Pragma("unroll") for (int i = 0; i < 4; i++) { \
-            _Pragma("unroll") for (int j = 0; j < 2; j++) acc[a_][b_][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fwl[b_][j], fah[i], acc[a_][b_][i][j], 0, 0, 0); \
-            _Pragma("unroll") for (int j = 0; j < 2; j++) acc[a_][b_][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fwh[b_][j], fal[i], acc[a_][b_][i][j], 0, 0, 0); \
-            _Pragma("unroll") for (int j = 0; j < 2; j++) acc[a_][b_][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fwh[b_][j], fah[i], acc[a_][b_][i][j], 0, 0, 0); }
+            _Pragma("unroll") for (int j = 0; j < 2; j++) acc[a_][b_][i][j] = PH8_MM(fwl[b_][j], fah[i], acc[a_][b_][i][j]); \
+            _Pragma("unroll") for (int j = 0; j < 2; j++) acc[a_][b_][i][j] = PH8_MM(fwh[b_][j], fal[i], acc[a_][b_][i][j]); \
+            _Pragma("unroll") for (int j = 0; j < 2; j++) acc[a_][b_][i][j] = PH8_MM(fwh[b_][j], fah[i], acc[a_][b_][i][j]); }
     // DMA_IN_M (experiment, not the default): the two LDS-DMA pieces of a phase pair are issued from inside the MFMA phase (behind
     // its first MFMA group) instead of from the load phase; each counted wait then sees one issue less in front of it (vmcnt(2) where
     // the load-phase form has vmcnt(4)).  Stamps (profiles/round2_gemm_phase_stamps.txt): the MFMA phases, not the load phases, set
@@ -376,6 +377,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16x3_ph8_kernel(const unsigned 
         PH8_END_M();
     }
 #undef PH8_MFMA_DMA
+#undef PH8_MM
     if (STAMP && stamps && lane == 0 && blockIdx.x < 256)
         for (int i = 0; i < 4; i++) stamps[((size_t)blockIdx.x * 8 + wave) * 4 + i] = sacc[i];
 #undef PH8_T
@@ -389,6 +391,26 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16x3_ph8_kernel(const unsigned 
     // rows): D row = 4*(lane>>4) + r, D col = lane&15, so a lane's four accumulator registers are FOUR CONSECUTIVE COLUMNS of one C
     // row -- the tile leaves as 16-byte stores (32 per wave, 16 rows x 64 B each) instead of 128 scalar ones.
     const int q4 = (lane >> 4) * 4;
+    if (!WFIRST) {   // measurement form only (A fragment first: D row = C row, D col = C column; scalar stores)
+#pragma unroll
+        for (int a = 0; a < 2; a++)
+#pragma unroll
+            for (int b = 0; b < 2; b++)
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+#pragma unroll
+                    for (int j = 0; j < 2; j++) {
+                        const int col = n0 + b * 128 + wc * 32 + j * 16 + l16;
+                        if (col >= N) continue;
+                        const float bv = bias ? bias[col] : 0.f;
+#pragma unroll
+                        for (int r = 0; r < 4; r++) {
+                            const int row = m0 + a * 128 + wr * 64 + i * 16 + q4 + r;
+                            if (row < M) C[(size_t)row * ldc + col] = acc[a][b][i][j][r] + bv;
+                        }
+                    }
+        return;
+    }
     const bool n_vec = (ldc % 4 == 0) && (((size_t)C & 15) == 0);
 #pragma unroll
     for (int a = 0; a < 2; a++)
@@ -420,6 +442,7 @@ int init_gemm_attributes() {
     MDD_HIP_CHECK(hipFuncSetAttribute((const void *)gemm_bf16x3_ph8_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 4 * 256 * XROW));
     MDD_HIP_CHECK(hipFuncSetAttribute((const void *)(gemm_bf16x3_ph8_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 4 * 256 * XROW));
     MDD_HIP_CHECK(hipFuncSetAttribute((const void *)(gemm_bf16x3_ph8_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 4 * 256 * XROW));
+    MDD_HIP_CHECK(hipFuncSetAttribute((const void *)(gemm_bf16x3_ph8_kernel<false, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 4 * 256 * XROW));
     return MDD_OK;
 }
 
@@ -512,6 +535,19 @@ extern "C" int mdd_diag_gemm_ph8(int M, int N, int K, int reps, unsigned seed, u
     }
     MDD_HIP_CHECK(hipMemcpy(mismatches_out, cnt, 4, hipMemcpyDeviceToHost));
     if (ms_out) { ms_out[0] = ms[0]; ms_out[1] = ms[1]; ms_out[2] = ms[2]; }
+    if (ms_out && getenv("MDD_GEMM_AFIRST")) {   // the 8-phase kernel with the A fragment as first MFMA operand (scalar C stores): ms_out[11]
+        float tot = 0.f;
+        for (int r = 0; r < reps; r++) {
+            MDD_HIP_CHECK(hipEventRecord(e0, nullptr));
+            hipLaunchKernelGGL((gemm_bf16x3_ph8_kernel<false, false, false>), grid, block, 2 * 4 * 256 * XROW, nullptr, A, A + (size_t)M * K, W, W + (size_t)N * K,
+                               (const float *)nullptr, C2, M, N, K, K, K, N, tn, (long long *)nullptr);
+            MDD_HIP_CHECK(hipEventRecord(e1, nullptr));
+            MDD_HIP_CHECK(hipEventSynchronize(e1));
+            float t = 0.f; MDD_HIP_CHECK(hipEventElapsedTime(&t, e0, e1));
+            if (r > 0) tot += t;
+        }
+        ms_out[11] = tot / (float)(reps - 1);
+    }
     if (ms_out && getenv("MDD_GEMM_STAMP")) {   // phase stamps of both forms: ms_out[3..6] (DMA in L) and [7..10] (DMA in M), mean cycles per K-tile and wave
         long long *sd = nullptr;
         MDD_HIP_CHECK(hipMalloc((void **)&sd, sizeof(long long) * 256 * 8 * 4));
