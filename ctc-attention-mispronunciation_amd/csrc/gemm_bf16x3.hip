@@ -411,6 +411,19 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16x3_ph8_kernel(const unsigned 
                     }
         return;
     }
+    if (STAMP && stamps == nullptr) {   // diagnostic form: no C stores at all (what the epilogue's HBM writes cost the launch); keep the accumulators alive
+        float keep = 0.f;
+#pragma unroll
+        for (int a = 0; a < 2; a++)
+#pragma unroll
+            for (int b = 0; b < 2; b++)
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+#pragma unroll
+                    for (int j = 0; j < 2; j++) keep += acc[a][b][i][j][0] + acc[a][b][i][j][1] + acc[a][b][i][j][2] + acc[a][b][i][j][3];
+        if (keep == 12345.678f) C[0] = keep;
+        return;
+    }
     const bool n_vec = (ldc % 4 == 0) && (((size_t)C & 15) == 0);
 #pragma unroll
     for (int a = 0; a < 2; a++)
@@ -547,6 +560,19 @@ extern "C" int mdd_diag_gemm_ph8(int M, int N, int K, int reps, unsigned seed, u
             if (r > 0) tot += t;
         }
         ms_out[11] = tot / (float)(reps - 1);
+    }
+    if (ms_out && getenv("MDD_GEMM_NOSTORE")) {   // ms_out[12]: the 8-phase kernel without its C stores
+        float tot = 0.f;
+        for (int r = 0; r < reps; r++) {
+            MDD_HIP_CHECK(hipEventRecord(e0, nullptr));
+            hipLaunchKernelGGL((gemm_bf16x3_ph8_kernel<false, true>), grid, block, 2 * 4 * 256 * XROW, nullptr, A, A + (size_t)M * K, W, W + (size_t)N * K,
+                               (const float *)nullptr, C2, M, N, K, K, K, N, tn, (long long *)nullptr);
+            MDD_HIP_CHECK(hipEventRecord(e1, nullptr));
+            MDD_HIP_CHECK(hipEventSynchronize(e1));
+            float t = 0.f; MDD_HIP_CHECK(hipEventElapsedTime(&t, e0, e1));
+            if (r > 0) tot += t;
+        }
+        ms_out[12] = tot / (float)(reps - 1);
     }
     if (ms_out && getenv("MDD_GEMM_STAMP")) {   // phase stamps of both forms: ms_out[3..6] (DMA in L) and [7..10] (DMA in M), mean cycles per K-tile and wave
         long long *sd = nullptr;
