@@ -449,6 +449,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16x3_ph8_kernel(const unsigned 
                 }
 }
 
+
 int init_gemm_attributes() {
     MDD_HIP_CHECK(hipFuncSetAttribute((const void *)gemm_bf16x3_glds256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 4 * 256 * XROW));
     MDD_HIP_CHECK(hipFuncSetAttribute((const void *)gemm_bf16x3_ph8_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 4 * 256 * XROW));

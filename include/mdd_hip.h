@@ -214,8 +214,8 @@ int mdd_adam_step(float *const *params, float *const *grads, float *const *exp_a
 
 /* ---- Diagnostics (test and measurement aid; no reference counterpart).
  * mdd_diag_gemm_ph8: race screen of the 8-phase projection GEMM -- the same pseudo-random operands through the single-barrier
- * kernel once and both forms of the 8-phase kernel `reps` times; *mismatches_out = C words that ever differed (must be 0;
- * tests/test_gpu_parity.py::test_gemm_8phase_race_screen).  ms_out (nullable, 3 floats): mean kernel time of the three forms. */
+ * kernel once and the 8-phase kernel (both DMA placements) `reps` times each; *mismatches_out = C words that ever
+ * differed (must be 0; tests/test_gpu_parity.py::test_gemm_8phase_race_screen).  ms_out (nullable, 16 floats): mean kernel times. */
 int mdd_diag_gemm_ph8(int M, int N, int K, int reps, unsigned seed, unsigned *mismatches_out, float *ms_out);
 
 #ifdef __cplusplus

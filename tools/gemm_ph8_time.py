@@ -11,7 +11,7 @@ from ctc_attention_mispronunciation_amd import _lib  # noqa: E402
 L = _lib.lib()
 torch.zeros(1).cuda()
 for M, N, K in ((128000, 3072, 768), (128000, 3072, 1952), (16000, 3072, 768), (20480, 3072, 512)):
-    bad, ms = C.c_uint(0), (C.c_float * 14)()
+    bad, ms = C.c_uint(0), (C.c_float * 16)()
     rc = L.mdd_diag_gemm_ph8(M, N, K, 6, 1, C.byref(bad), ms)
     fl = 2.0 * M * N * K
     print("M=%d N=%d K=%d rc=%d mismatches=%d  single-barrier %.3f ms (%.0f TF)  ph8/L %.3f ms (%.0f TF)  ph8/M %.3f ms (%.0f TF)" %
