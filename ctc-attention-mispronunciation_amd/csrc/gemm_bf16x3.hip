@@ -562,6 +562,20 @@ extern "C" int mdd_diag_gemm_ph8(int M, int N, int K, int reps, unsigned seed, u
         }
         ms_out[11] = tot / (float)(reps - 1);
     }
+    if (ms_out && getenv("MDD_GEMM_T128")) {   // ms_out[14]: the 128x128 kernel (two workgroups per CU) on the same problem
+        const int tm1 = (M + XBM - 1) / XBM, tn1 = (N + XBN - 1) / XBN;
+        float tot = 0.f;
+        for (int r = 0; r < reps; r++) {
+            MDD_HIP_CHECK(hipEventRecord(e0, nullptr));
+            hipLaunchKernelGGL(gemm_bf16x3_glds_kernel<0>, dim3(tm1 * tn1), dim3(256), 0, nullptr, A, A + (size_t)M * K, W, W + (size_t)N * K, (const float *)nullptr, C2,
+                               (unsigned short *)nullptr, (unsigned short *)nullptr, M, N, K, K, K, N, 0l, 0l, 0l, tn1);
+            MDD_HIP_CHECK(hipEventRecord(e1, nullptr));
+            MDD_HIP_CHECK(hipEventSynchronize(e1));
+            float t = 0.f; MDD_HIP_CHECK(hipEventElapsedTime(&t, e0, e1));
+            if (r > 0) tot += t;
+        }
+        ms_out[14] = tot / (float)(reps - 1);
+    }
     if (ms_out && getenv("MDD_GEMM_NOSTORE")) {   // ms_out[12]: the 8-phase kernel without its C stores
         float tot = 0.f;
         for (int r = 0; r < reps; r++) {

@@ -16,6 +16,8 @@ for M, N, K in ((128000, 3072, 768), (128000, 3072, 1952), (16000, 3072, 768), (
     fl = 2.0 * M * N * K
     print("M=%d N=%d K=%d rc=%d mismatches=%d  single-barrier %.3f ms (%.0f TF)  ph8/L %.3f ms (%.0f TF)  ph8/M %.3f ms (%.0f TF)" %
           (M, N, K, rc, bad.value, ms[0], fl / ms[0] / 1e9, ms[1], fl / ms[1] / 1e9, ms[2], fl / ms[2] / 1e9))
+    if os.environ.get("MDD_GEMM_T128"):
+        print("   128x128 kernel, two workgroups per CU: %.3f ms (%.0f TF)" % (ms[14], fl / ms[14] / 1e9))
     if os.environ.get("MDD_GEMM_AFIRST"):
         print("   ph8/L with the A fragment as first MFMA operand (scalar C stores): %.3f ms (%.0f TF)" % (ms[11], fl / ms[11] / 1e9))
     if os.environ.get("MDD_GEMM_NOSTORE"):
