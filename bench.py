@@ -75,7 +75,7 @@ class Ctx(object):
             self.local = self.local % ndev
         torch.cuda.set_device(self.local)
         self.dist = None
-        if self.world > 1:
+        if self.world > 1 or os.environ.get("MDD_FORCE_DIST"):    # MDD_FORCE_DIST=1: a one-rank process group, to exercise the RCCL calls on a one-GPU box
             import torch.distributed as dist
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -114,7 +114,7 @@ class DecodeJob(object):
         self.decoder_kind = kind
         self.decoder = (BeamDecoder(self.i2c, beam_width=BEAM_W, blank_index=0, space_idx=-1, lm_path=arpa, lm_alpha=0.0)
                         if kind == "beam" else GreedyDecoder(self.i2c, space_idx=-1, blank_index=0))
-        self.gather = gather and ctx.world > 1
+        self.gather = gather and ctx.dist is not None
         self.s_fwd, self.s_dec = torch.cuda.Stream(), torch.cuda.Stream()
         self.ev_fwd = [torch.cuda.Event() for _ in range(2)]
         self.ev_dec = [torch.cuda.Event() for _ in range(2)]
@@ -305,6 +305,8 @@ class DecodeJob(object):
         ok = True
         for bf in ([r["bf"] for r in self.rag if "bf" in r] if self.ragged else list(self.sets.values())):
             for k in range(2):
+                if self.count < 2 and k >= self.count:
+                    continue                                  # slot never used
                 own = bf.gathered[k][self.ctx.rank]
                 ok = ok and bool(torch.equal(own, bf.logp[k]))
                 ok = ok and all(not torch.equal(bf.gathered[k][r], own) for r in range(self.ctx.world) if r != self.ctx.rank)

@@ -44,6 +44,11 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(LstmStepArgs a, int s) {
     const float *hprev = a.hbuf + ((size_t)((s & 1) ^ 1) * 2 + d) * B * H;
     float *hnext = a.hbuf + ((size_t)(s & 1) * 2 + d) * B * H;
 
+    // the epilogue's operands do not depend on the product: request them first, so the step pays one memory round trip, not two
+    const int u = ut * 4 + kq;
+    const size_t ci = ((size_t)d * B + bc) * H + u;
+    const float4 g4 = *reinterpret_cast<const float4 *>(a.gx + (((size_t)t * B + bc) * 2 + d) * 4 * H + u * 4);
+    const float cold = s > 0 ? a.cbuf[ci] : 0.f;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     if (s > 0) {
         const float *wp = a.whh + ((size_t)d * 4 * H + ut * 16 + li) * H + kq * KQ;  // A[row li][k quarter kq]
@@ -76,10 +81,6 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(LstmStepArgs a, int s) {
     }
     // D layout: col = lane&15 (batch), row = 4*(lane>>4) + r  ->  unit = ut*4 + (lane>>4), gate = r
     if (b < B) {
-        const int u = ut * 4 + kq;
-        const float4 g4 = *reinterpret_cast<const float4 *>(a.gx + (((size_t)t * B + b) * 2 + d) * 4 * H + u * 4);
-        const size_t ci = ((size_t)d * B + b) * H + u;
-        const float cold = s > 0 ? a.cbuf[ci] : 0.f;
         const float ig = sigmoid_f(acc[0] + g4.x), fg = sigmoid_f(acc[1] + g4.y);
         const float gg = tanhf(acc[2] + g4.z), og = sigmoid_f(acc[3] + g4.w);
         const bool hold = d && a.seqlen && t >= a.seqlen[b];     // reverse direction has not reached this row's last step yet

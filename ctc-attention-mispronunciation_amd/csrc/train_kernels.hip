@@ -501,6 +501,20 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_step_kernel(LstmBwdArgs a, in
     const int t = d ? s : (T - 1 - s);
     const int tprev = d ? s - 1 : (T - s);                 // time visited by the previous launch
     const int li = lane & 15, kq = lane >> 4;
+    // the cell backward's operands (saved gates, cell states, the carried cell gradient, the upstream gradient) do not depend on the
+    // product: every thread requests those of its (unit, batch) element before the contraction, one memory round trip per step
+    const int ul = tid >> 4, bl = tid & 15;
+    const int u = kt * 16 + ul, b = b0 + bl;
+    const bool live = u < H && b < B;
+    const int uc = min(u, H - 1), bcl = min(b, B - 1);
+    const size_t si = (((size_t)t * B + bcl) * 2 + d) * H + uc;
+    const float4 gt = *reinterpret_cast<const float4 *>(a.gates + si * 4);
+    const float ct = a.cst[si];
+    const int tp = d ? t + 1 : t - 1;                       // the forward pass's previous time of this direction
+    const float cprev = (tp >= 0 && tp < T) ? a.cst[(((size_t)tp * B + bcl) * 2 + d) * H + uc] : 0.f;
+    const size_t ci = ((size_t)d * B + bcl) * H + uc;
+    const float dc_in = s > 0 ? a.dc[ci] : 0.f;
+    const float dout_v = a.dout[((size_t)t * B + bcl) * 2 * H + d * H + uc];
     f32x4v acc = {0.f, 0.f, 0.f, 0.f};
     if (s > 0) {
         // wave w contracts n in [w*G/4, (w+1)*G/4); inside the wave the four 16-lane groups take contiguous quarters of that range
@@ -532,18 +546,9 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_step_kernel(LstmBwdArgs a, in
     for (int r = 0; r < 4; r++) red[wave][(4 * kq + r) * 16 + li] = acc[r];
     __syncthreads();
     // one thread per (unit, batch) of the tile
-    const int ul = tid >> 4, bl = tid & 15;
-    const int u = kt * 16 + ul, b = b0 + bl;
-    if (u >= H || b >= B) return;
+    if (!live) return;
     const float dh_rec = (red[0][ul * 16 + bl] + red[1][ul * 16 + bl]) + (red[2][ul * 16 + bl] + red[3][ul * 16 + bl]);
-    const float dh = a.dout[((size_t)t * B + b) * 2 * H + d * H + u] + dh_rec;
-    const size_t si = (((size_t)t * B + b) * 2 + d) * H + u;
-    const float4 gt = *reinterpret_cast<const float4 *>(a.gates + si * 4);
-    const float ct = a.cst[si];
-    const int tp = d ? t + 1 : t - 1;                       // the forward pass's previous time of this direction
-    const float cprev = (tp >= 0 && tp < T) ? a.cst[(((size_t)tp * B + b) * 2 + d) * H + u] : 0.f;
-    const size_t ci = ((size_t)d * B + b) * H + u;
-    const float dc_in = s > 0 ? a.dc[ci] : 0.f;
+    const float dh = dout_v + dh_rec;
     const float th = tanhf(ct);
     const float d_o = dh * th * gt.w * (1.f - gt.w);
     const float dcell = dh * gt.w * (1.f - th * th) + dc_in;

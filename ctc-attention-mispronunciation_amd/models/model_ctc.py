@@ -5,7 +5,8 @@ signature and return layout ([T/2, B, C] log-probabilities) as the reference, so
 ``from models.model_ctc import *`` in AA/infer.py:24 can be pointed here unchanged.  The torch
 modules below are parameter containers only (they give the 61 reference key names and make
 ``load_state_dict`` / ``.to()`` work); the arithmetic of ``forward`` runs in hand-written gfx950
-kernels behind the C ABI of libmdd_hip.so (include/mdd_hip.h).  Eval mode only.
+kernels behind the C ABI of libmdd_hip.so (include/mdd_hip.h): eval mode through mdd_forward, train mode (BatchNorm on batch
+statistics, dropout, differentiable w.r.t. every parameter) through mdd_train_forward / mdd_train_backward (train.py).
 
 AA/infer.py also relies on this module re-exporting ``math`` (infer.py:342) -- kept, together with
 the other names the reference module exposes through ``import *``.

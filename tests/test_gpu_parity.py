@@ -915,3 +915,28 @@ def test_fused_batches_full_size_and_reference_golden():
     lp = m9.forward_fused(_cuda(X), _cuda(X1), _cuda(fr), _cuda(cn), sync_errors=True).cpu().numpy()
     np.testing.assert_allclose(lp[:, :B9], ref, rtol=0, atol=TOL)
     np.testing.assert_array_equal(lp[:32, B9:], m9.forward(_cuda(xs), _cuda(x1s)).cpu().numpy())
+
+
+def test_fused_batches_edge_shapes():
+    """mdd_forward_fused at the edges: single-utterance batches, the shortest legal batch (one posterior frame, one canonical
+    phoneme), a batch that alone fills the common shape, 17 + 1 + 33 rows (team tiles that are not multiples of 16)."""
+    geom = synth.Geometry(**synth.REFERENCE)
+    sd = synth.synth_state_dict(geom, seed=31)
+    shapes = [(17, 20, 3), (1, 2, 1), (33, 8, 5), (1, 20, 5)]
+    batches = _ragged_batches(geom, shapes, seed=77)
+    for precision in ("bf16x3", "f32"):
+        m = _hip().HipModel(geom, sd, precision=precision)
+        Bt, Tm, Lm = sum(s[0] for s in shapes), max(s[1] for s in shapes), max(s[2] for s in shapes)
+        X = np.zeros((Bt, Tm, geom.feat), dtype=np.float32); X1 = np.zeros((Bt, Lm), dtype=np.int64)
+        fr, cn = np.zeros(Bt, dtype=np.int32), np.zeros(Bt, dtype=np.int32)
+        r = 0
+        for (x, x1, _), (b, T, L) in zip(batches, shapes):
+            X[r:r + b, :T] = x; X1[r:r + b, :L] = x1; fr[r:r + b] = T // 2; cn[r:r + b] = L
+            r += b
+        fused = m.forward_fused(_cuda(X), _cuda(X1), _cuda(fr), _cuda(cn), sync_errors=True).cpu().numpy()
+        r = 0
+        for (x, x1, _), (b, T, L) in zip(batches, shapes):
+            own = m.forward(_cuda(x), _cuda(x1), sync_errors=True).cpu().numpy()
+            np.testing.assert_array_equal(fused[:T // 2, r:r + b], own)
+            np.testing.assert_allclose(own, oracle.forward(sd, x, x1), rtol=0, atol=TOL)
+            r += b
