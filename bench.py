@@ -80,10 +80,23 @@ class Ctx(object):
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
             backend = os.environ.get("MDD_DIST_BACKEND", "nccl")   # "nccl" is RCCL on ROCm
-            if backend == "nccl":
-                dist.init_process_group("nccl", rank=self.rank, world_size=self.world, device_id=torch.device("cuda", self.local))
-            else:
-                dist.init_process_group(backend, rank=self.rank, world_size=self.world)
+            # The pool exports NCCL_DEBUG=VERSION and RCCL prints its banner on stdout when the communicator is created; stdout must carry
+            # ONE JSON line, so file descriptor 1 points at stderr until the first collective has run (C stdio flushed before it is restored).
+            import ctypes
+            sys.stdout.flush()
+            saved_fd = os.dup(1)
+            os.dup2(2, 1)
+            try:
+                if backend == "nccl":
+                    dist.init_process_group("nccl", rank=self.rank, world_size=self.world, device_id=torch.device("cuda", self.local))
+                else:
+                    dist.init_process_group(backend, rank=self.rank, world_size=self.world)
+                dist.barrier()
+                torch.cuda.synchronize()
+            finally:
+                ctypes.CDLL(None).fflush(None)
+                os.dup2(saved_fd, 1)
+                os.close(saved_fd)
             self.dist = dist
 
     def barrier(self):
