@@ -49,6 +49,8 @@ def parse():
     ap.add_argument("--steps", type=int, default=256)
     ap.add_argument("--warmup", type=int, default=32)
     ap.add_argument("--workload", default="joint64", choices=["joint64", "greedy32", "ctc256", "train32"])
+    ap.add_argument("--train-precision", default="f32", choices=["f32", "bf16x3"],
+                    help="train32: exact fp32 (as the reference trains) or the large contractions as split-bf16 x3 (BASELINE configs[4] names bf16)")
     ap.add_argument("--hidden", type=int, default=384)
     ap.add_argument("--fuse", type=int, default=8, help="reference-sized batches carried by one launch sequence")
     ap.add_argument("--ragged", action="store_true", help="headline on the ragged set (per-batch padding, unpadded frames counted)")
@@ -455,6 +457,7 @@ def train_workload(ctx, args):
     model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
     model = model.cuda().train()
     model.strict_errors = False                                     # no host synchronisation inside the step
+    model.train_precision = args.train_precision
     loss_fn, opt = build_training(model)
     x, x1, frac, _ = synth.synth_batch(geom, B=B, T=T, L=L, seed=1234 + ctx.rank, ragged=False)
     rs = np.random.Generator(np.random.PCG64(7 + ctx.rank))
@@ -529,7 +532,9 @@ def main():
             print(json.dumps({"metric": "phoneme-frames/sec training step (fwd + CTC + bwd + all-reduce + Adam)", "value": round(world * frames / dt, 1),
                               "unit": "phoneme-frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                               "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-                              "dtype": "f32 (exact fp32 MFMA; the reference trains in fp32)", "data": "synthetic",
+                              "dtype": ("f32 (exact fp32 MFMA; the reference trains in fp32)" if args.train_precision == "f32" else
+                                        "f32 with the projection GEMMs (forward, dX, dW_ih) as split-bf16 x3 on the bf16 matrix cores; recurrences, "
+                                        "BatchNorm, attention, CTC in fp32/fp64"), "data": "synthetic",
                               "config": {"workload": "training step, B=32 per GPU x 10 s (global batch 32 x n_gpus; BASELINE configs[4] = 8 x 32), H=%d, L=40, dropout 0.2, "
                                                      "Adam lr 1e-3 wd 5e-4" % args.hidden, **info},
                               "roofline": {"kernel": "training step (all kernels)", "bound": "mfma", "achieved": round(flop / (dt / args.steps) / 1e12, 2),

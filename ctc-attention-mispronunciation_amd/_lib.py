@@ -17,7 +17,7 @@ EXPORTS = (
     "mdd_set_precision", "mdd_get_precision", "mdd_stack_len", "mdd_stack_skip", "mdd_len_frames", "mdd_forward", "mdd_forward_fused", "mdd_forward_raw", "mdd_forward_num_stages", "mdd_forward_profile", "mdd_tap", "mdd_tap_copy", "mdd_enable_taps", "mdd_sync",
     "mdd_greedy", "mdd_beam", "mdd_ctc_loss", "mdd_ctc_workspace_bytes", "mdd_align", "mdd_align_batch", "mdd_eval_batch", "mdd_fbank_num_frames", "mdd_fbank",
     "mdd_train_create", "mdd_train_destroy", "mdd_train_num_tensors", "mdd_train_tensor_info", "mdd_train_num_masks", "mdd_train_mask_bytes",
-    "mdd_train_forward", "mdd_train_backward", "mdd_train_sync", "mdd_adam_step",
+    "mdd_train_forward", "mdd_train_backward", "mdd_train_sync", "mdd_train_set_precision", "mdd_adam_step",
     "mdd_diag_gemm_ph8",
 )
 
@@ -92,6 +92,7 @@ def lib():
     L.mdd_train_forward.argtypes = [vp, vp, vp, i32, i32, vp, i32, vp, C.c_uint64, C.c_float, vp, vp]
     L.mdd_train_backward.argtypes = [vp, vp, vp, vp, vp]
     L.mdd_train_sync.argtypes = [vp, vp]
+    L.mdd_train_set_precision.argtypes = [vp, C.c_int32]
     L.mdd_adam_step.argtypes = [vp, vp, vp, vp, vp, i32, i32, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, vp]
     _lib = L
     return L

@@ -7,6 +7,7 @@
 // Parameters stay where the caller keeps them (the drop-in CTC_Model's torch Parameters): every call receives the device
 // pointers of the 55 float tensors of the state_dict in the order mdd_train_tensor_info() reports, and mdd_train_backward
 // writes one gradient tensor per parameter.  The handle owns the saved activations of the last forward.
+#include <stdlib.h>
 #include <string.h>
 
 #include <string>
@@ -47,6 +48,8 @@ struct mdd_train_ws {
     std::vector<mdd::Buf> xin, hraw, pd, gates, cst, wihp, whhp, whht;    // per rnn layer (index layers = the text encoder)
     mdd::Buf tbias;
     mdd::Buf d_a, d_b, d_c, part, dtext, dkey;      // backward temporaries
+    mdd::Buf xs_a, xs_b;               // split-bf16 operand planes of the flagged variant's GEMMs (hi plane, then lo plane)
+    int precision = 0;                 // 0: exact fp32 MFMA everywhere (the reference trains in fp32); 1: the large contractions as split-bf16 x3
     int *err_flag = nullptr;           // set by the embedding gather on an id outside the table
     mdd::Buf masks;                    // generated dropout masks (bytes)
     std::vector<const unsigned char *> mask_ptr;
@@ -55,7 +58,7 @@ struct mdd_train_ws {
     const float *x = nullptr;
     ~mdd_train_ws() {
         mdd::Buf *all[] = {&z0, &a0, &col1, &w1r, &z1, &a1, &seq0, &gx, &dgx, &hb, &cb, &emb, &text, &key, &att, &cat, &ycat, &logits, &logp, &stats,
-                           &tbias, &d_a, &d_b, &d_c, &part, &masks, &dtext, &dkey};
+                           &tbias, &d_a, &d_b, &d_c, &part, &masks, &dtext, &dkey, &xs_a, &xs_b};
         for (auto *b : all) b->release();
         for (auto *v : {&xin, &hraw, &pd, &gates, &cst, &wihp, &whhp, &whht}) for (auto &b : *v) b.release();
         if (dacc) (void)hipFree(dacc);
@@ -114,9 +117,44 @@ static int gemm_tn(mdd_train_ws *w, const float *A, int lda, const float *Bm, in
     return launch_reduce_parts(w->part.p, parts, (size_t)M * N, C, st);
 }
 
+// C[M,N] = opA . opB^T for the large contractions of the step; opA[m,k] = ta ? A[k*lda + m] : A[m*lda + k], opB[n,k] likewise.
+// precision 0: exact fp32 (gemm_f32 / split-K for the weight gradients).  precision 1 and a problem large enough to fill 256 x 256
+// tiles: both operands are written as bf16 hi/lo planes with the contraction along their rows' contiguous axis (transposed on the way
+// when the operand is stored [K, *]) and the product runs on the bf16 matrix cores (3 MFMA flops per flop, fp32 accumulate).
+static int gemm_big(mdd_train_ws *w, bool ta, bool tb, const float *A, int lda, const float *Bm, int ldb, const float *bias, float *C, int ldc, int M, int N,
+                    int K, hipStream_t st) {
+    const bool x3 = w->precision == 1 && M >= 256 && N >= 256 && K >= 256 && ldc % 4 == 0 && (size_t)M * N * K >= ((size_t)1 << 30);
+    if (!x3) {
+        if (ta && tb && !bias && ldc == N) return gemm_tn(w, A, lda, Bm, ldb, C, M, N, K, st);
+        return launch_gemm_f32(ta, tb, A, Bm, bias, C, M, N, K, lda, ldb, ldc, 1, 0, 0, 0, false, st);
+    }
+    // few output tiles and a long contraction (the weight gradients): the K axis is cut into S chunks that run as a batch of partial
+    // products (the planes' K axis is contiguous, so chunk s starts s*Kc elements into every row), summed afterwards.
+    const int tiles = ((M + 127) / 128) * ((N + 127) / 128);
+    int S = 1;
+    if (tiles < 256 && K > 2048 && !bias && ldc == N) S = std::min(16, std::max(1, std::min(K / 1024, 512 / tiles)));
+    const int Kc = ((K + S - 1) / S + 31) / 32 * 32, Kp = S * Kc;
+    if (int rc = w->xs_a.need((size_t)M * Kp)) return rc;
+    if (int rc = w->xs_b.need((size_t)N * Kp)) return rc;
+    SplitPtr sa{reinterpret_cast<unsigned short *>(w->xs_a.p), reinterpret_cast<unsigned short *>(w->xs_a.p) + (size_t)M * Kp};
+    SplitPtr sb{reinterpret_cast<unsigned short *>(w->xs_b.p), reinterpret_cast<unsigned short *>(w->xs_b.p) + (size_t)N * Kp};
+    if (int rc = ta ? launch_transpose_split(A, lda, K, M, Kp, sa.hi, sa.lo, st) : launch_split_rows(A, lda, (size_t)M, K, Kp, sa.hi, sa.lo, st)) return rc;
+    if (int rc = tb ? launch_transpose_split(Bm, ldb, K, N, Kp, sb.hi, sb.lo, st) : launch_split_rows(Bm, ldb, (size_t)N, K, Kp, sb.hi, sb.lo, st)) return rc;
+    if (S == 1) return launch_gemm_bf16x3(sa, sb, bias, C, nullptr, M, N, Kp, Kp, Kp, ldc, 1, 0, 0, 0, st);
+    if (int rc = w->part.need((size_t)S * M * N)) return rc;
+    if (int rc = launch_gemm_bf16x3(sa, sb, nullptr, w->part.p, nullptr, M, N, Kc, Kp, Kp, N, S, Kc, Kc, (long)M * N, st)) return rc;
+    return launch_reduce_parts(w->part.p, S, (size_t)M * N, C, st);
+}
+
 }  // namespace mdd
 
 using namespace mdd;
+
+extern "C" int mdd_train_set_precision(mdd_train_ws *w, int32_t mode) {
+    if (!w || (mode != 0 && mode != 1)) { set_error("mdd_train_set_precision: mode must be 0 (exact fp32) or 1 (split-bf16 x3 contractions)"); return MDD_ERR_ARG; }
+    w->precision = mode;
+    return MDD_OK;
+}
 
 extern "C" int mdd_train_create(const mdd_config *cfg, int device, mdd_train_ws **out) {
     if (!cfg || !out) { set_error("mdd_train_create: null argument"); return MDD_ERR_ARG; }
@@ -126,6 +164,7 @@ extern "C" int mdd_train_create(const mdd_config *cfg, int device, mdd_train_ws 
     MDD_HIP_CHECK(hipSetDevice(device));
     mdd_train_ws *w = new mdd_train_ws();
     w->cfg = *cfg; w->device = device;
+    { const char *pr = getenv("MDD_TRAIN_PRECISION"); if (pr && (!strcmp(pr, "bf16x3") || !strcmp(pr, "1"))) w->precision = 1; }
     build_info(w);
     const int nl = cfg->layers + 1;
     w->xin.resize(nl); w->hraw.resize(nl); w->pd.resize(nl); w->gates.resize(nl); w->cst.resize(nl); w->wihp.resize(nl); w->whhp.resize(nl); w->whht.resize(nl);
@@ -228,7 +267,7 @@ extern "C" int mdd_train_forward(mdd_train_ws *w, float *const *tensors, const f
         }
         TRY(launch_pack_gates(P(r + ".rnn.weight_ih_l0"), P(r + ".rnn.weight_ih_l0_reverse"), w->wihp[n].p, H, K, st));
         TRY(launch_pack_gates(P(r + ".rnn.weight_hh_l0"), P(r + ".rnn.weight_hh_l0_reverse"), w->whhp[n].p, H, H, st));
-        TRY(launch_gemm_f32(false, false, xin, w->wihp[n].p, nullptr, w->gx.p, (int)R, G2, K, K, K, G2, 1, 0, 0, 0, false, st));
+        TRY(gemm_big(w, false, false, xin, K, w->wihp[n].p, K, nullptr, w->gx.p, G2, (int)R, G2, K, st));
         LstmStepArgs a;
         a.gx = w->gx.p; a.whh = w->whhp[n].p; a.hbuf = w->hb.p; a.cbuf = w->cb.p; a.out = w->hraw[n].p; a.out_raw = w->hraw[n].p;
         a.out_split = SplitPtr{nullptr, nullptr}; a.oscale = nullptr; a.oshift = nullptr; a.T = Tp; a.B = B; a.H = H;
@@ -245,7 +284,7 @@ extern "C" int mdd_train_forward(mdd_train_ws *w, float *const *tensors, const f
     TRY(w->d_a.need(G2));
     TRY(launch_pack_gates(P("lstm_embeds.bias_hh_l0"), P("lstm_embeds.bias_hh_l0_reverse"), w->d_a.p, H, 1, st));
     TRY(launch_copy_cols(w->d_a.p, G2, 0, w->tbias.p, G2, 0, 1, G2, true, st));
-    TRY(launch_gemm_f32(false, false, w->emb.p, w->wihp[nl].p, w->tbias.p, w->gx.p, (int)Rt, G2, E, E, E, G2, 1, 0, 0, 0, false, st));
+    TRY(gemm_big(w, false, false, w->emb.p, E, w->wihp[nl].p, E, w->tbias.p, w->gx.p, G2, (int)Rt, G2, E, st));
     {
         LstmStepArgs a;
         a.gx = w->gx.p; a.whh = w->whhp[nl].p; a.hbuf = w->hb.p; a.cbuf = w->cb.p; a.out = w->hraw[nl].p; a.out_raw = w->hraw[nl].p;
@@ -279,17 +318,17 @@ static int lstm_backward(mdd_train_ws *w, int n, int Tn, int B, int K, const flo
     TRY(launch_lstm_bwd(a, st));
     // dWih' [2*4H, K] = DG^T . xin ;  dWhh'[d] [4H, H] = DG_d^T . h_prev_d  (h_prev = the layer's raw output one step earlier in that direction)
     TRY(w->d_b.need((size_t)G2 * std::max(K, H)));
-    TRY(gemm_tn(w, w->dgx.p, G2, xin, K, w->d_b.p, G2, K, (int)rows, st));
+    TRY(gemm_big(w, true, true, w->dgx.p, G2, xin, K, nullptr, w->d_b.p, K, G2, K, (int)rows, st));
     TRY(launch_unpack_gates(w->d_b.p, g_ih_f, g_ih_r, H, K, st));
     if (Tn > 1) {
         const size_t rows1 = (size_t)(Tn - 1) * B;
-        TRY(gemm_tn(w, w->dgx.p + (size_t)B * G2, G2, w->hraw[n].p, H2, w->d_b.p, G, H, (int)rows1, st));                               // forward direction: t = 1.., h_{t-1}
-        TRY(gemm_tn(w, w->dgx.p + G, G2, w->hraw[n].p + (size_t)B * H2 + H, H2, w->d_b.p + (size_t)G * H, G, H, (int)rows1, st));       // reverse: t = 0..T-2, h_{t+1}
+        TRY(gemm_big(w, true, true, w->dgx.p + (size_t)B * G2, G2, w->hraw[n].p, H2, nullptr, w->d_b.p, H, G, H, (int)rows1, st));                  // forward direction: t = 1.., h_{t-1}
+        TRY(gemm_big(w, true, true, w->dgx.p + G, G2, w->hraw[n].p + (size_t)B * H2 + H, H2, nullptr, w->d_b.p + (size_t)G * H, H, G, H, (int)rows1, st));   // reverse: t = 0..T-2, h_{t+1}
     } else {
         MDD_HIP_CHECK(hipMemsetAsync(w->d_b.p, 0, sizeof(float) * G2 * H, st));
     }
     TRY(launch_unpack_gates(w->d_b.p, g_hh_f, g_hh_r, H, H, st));
-    if (dxin) TRY(launch_gemm_f32(false, true, w->dgx.p, w->wihp[n].p, nullptr, dxin, (int)rows, K, G2, G2, K, K, 1, 0, 0, 0, false, st));
+    if (dxin) TRY(gemm_big(w, false, true, w->dgx.p, G2, w->wihp[n].p, K, nullptr, dxin, K, (int)rows, K, G2, st));
     return MDD_OK;
 }
 

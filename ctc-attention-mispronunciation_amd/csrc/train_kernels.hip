@@ -570,6 +570,47 @@ int launch_lstm_bwd(const LstmBwdArgs &a, hipStream_t st) {
     return MDD_OK;
 }
 
+// ------------------------------------------------------------------------------------------------ split-bf16 operands for the training GEMMs
+// The flagged split-bf16 variant of the training step sends its large contractions through the projection GEMM of the decode path
+// (gemm_bf16x3.hip: C = A . W^T with hi/lo bf16 planes, K a multiple of 32).  These two kernels make the planes of an fp32 matrix:
+// as it stands (rows x cols, the contraction along the columns, zero-padded to cols_pad) or transposed (the contraction along the ROWS:
+// out[c][r] = src[r][c], zero-padded to rows_pad), which turns the NN and TN products of the backward pass into the NT form.
+__device__ __forceinline__ void split_store(float v, unsigned short *hi, unsigned short *lo, size_t i) {
+    __bf16 h = (__bf16)v, l = (__bf16)(v - (float)h);
+    hi[i] = *reinterpret_cast<unsigned short *>(&h);
+    lo[i] = *reinterpret_cast<unsigned short *>(&l);
+}
+__global__ void split_rows_kernel(const float *__restrict__ src, int ld, size_t rows, int cols, int cols_pad, unsigned short *__restrict__ hi,
+                                  unsigned short *__restrict__ lo) {
+    const size_t n = rows * cols_pad;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t r = i / cols_pad; const int c = (int)(i % cols_pad);
+        split_store(c < cols ? src[r * ld + c] : 0.f, hi, lo, i);
+    }
+}
+__global__ __launch_bounds__(256) void transpose_split_kernel(const float *__restrict__ src, int ld, int rows, int cols, int rows_pad,
+                                                              unsigned short *__restrict__ hi, unsigned short *__restrict__ lo) {
+    __shared__ float tile[32][33];
+    const int r0 = blockIdx.x * 32, c0 = blockIdx.y * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8 threads
+    for (int j = ty; j < 32; j += 8) {
+        const int r = r0 + j, c = c0 + tx;
+        tile[j][tx] = (r < rows && c < cols) ? src[(size_t)r * ld + c] : 0.f;
+    }
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8) {
+        const int c = c0 + j, r = r0 + tx;
+        if (c < cols && r < rows_pad) split_store(tile[tx][j], hi, lo, (size_t)c * rows_pad + r);
+    }
+}
+int launch_split_rows(const float *src, int ld, size_t rows, int cols, int cols_pad, unsigned short *hi, unsigned short *lo, hipStream_t st) {
+    hipLaunchKernelGGL(split_rows_kernel, dim3(4096), dim3(256), 0, st, src, ld, rows, cols, cols_pad, hi, lo);
+    MDD_LAUNCH_CHECK(); return MDD_OK;
+}
+int launch_transpose_split(const float *src, int ld, int rows, int cols, int rows_pad, unsigned short *hi, unsigned short *lo, hipStream_t st) {
+    hipLaunchKernelGGL(transpose_split_kernel, dim3((rows_pad + 31) / 32, (cols + 31) / 32), dim3(256), 0, st, src, ld, rows, cols, rows_pad, hi, lo);
+    MDD_LAUNCH_CHECK(); return MDD_OK;
+}
+
 // ------------------------------------------------------------------------------------------------ Adam (torch.optim.Adam semantics, L2 weight decay)
 // g' = g + wd * p;  m = b1 m + (1-b1) g';  v = b2 v + (1-b2) g'^2;  p -= lr / (1 - b1^t) * m / (sqrt(v) / sqrt(1 - b2^t) + eps)
 __global__ void adam_kernel(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ m, float *__restrict__ v, size_t n, float lr, float b1,

@@ -109,6 +109,10 @@ def model_forward_train(model, x, x1, masks=None, seed=None):
     if h is None or h.device_index != index:
         h = TrainHandle(model._config(), index)
         model._train_handle = h
+    want = getattr(model, "train_precision", None)          # None: the library default (exact fp32, or MDD_TRAIN_PRECISION)
+    if want is not None and want != getattr(h, "precision", None):
+        _lib.check(_lib.lib().mdd_train_set_precision(h.handle, {"f32": 0, "bf16x3": 1}[want]))
+        h.precision = want
     sd = dict(model.named_parameters())
     sd.update(dict(model.named_buffers()))
     tensors = []

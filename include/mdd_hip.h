@@ -197,9 +197,12 @@ int mdd_eval_batch(const int32_t *dec, const int32_t *dec_len, const int32_t *la
  *                               by 1/B as train_ctc.py:73-74 divides the loss) -> one gradient per parameter into grads[i]
  *                               (entries of running-statistics buffers are ignored and may be NULL)
  *   mdd_adam_step               torch.optim.Adam over n tensors (train_ctc.py:187: lr 1e-3, weight_decay 5e-4 added to the gradient)
- * Arithmetic is exact fp32 (v_mfma_f32_*), as the reference trains. */
+ * Arithmetic is exact fp32 (v_mfma_f32_*), as the reference trains; mdd_train_set_precision(w, 1) (or MDD_TRAIN_PRECISION=bf16x3 at create)
+ * sends the large projections and their two backward products through the split-bf16 x3 matrix-core GEMM of the decode path instead
+ * (operands to 16 mantissa bits, fp32 accumulate); everything else stays fp32 in both modes. */
 typedef struct mdd_train_ws mdd_train_ws;
 int mdd_train_create(const mdd_config *cfg, int device, mdd_train_ws **out);
+int mdd_train_set_precision(mdd_train_ws *w, int32_t mode);   /* 0 exact fp32 (default), 1 split-bf16 x3 contractions */
 void mdd_train_destroy(mdd_train_ws *w);
 int32_t mdd_train_num_tensors(mdd_train_ws *w);
 int mdd_train_tensor_info(mdd_train_ws *w, int32_t i, char *key, int32_t cap, int64_t *numel, int32_t *is_buffer);

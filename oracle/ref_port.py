@@ -132,10 +132,11 @@ def beam(logp, lens, int2char, lm, beam_width=10, alpha=0.0, blank=0):
 # Train-mode restatement (torch autograd on ATen CPU ops) -- the checker of the HIP training step on shapes that have no
 # golden: CTC_Model.forward with BatchNorm on batch statistics and Dropout realised by GIVEN masks (1 = keep; the kept values are
 # scaled by 1/(1-p), as nn.Dropout does), nn.CTCLoss(sum)/B, backward.  Pinned against the real reference by tests/golden/g11_*.
-def train_step(sd_np, x, x1, masks, targets, in_len, tgt_len, p_drop, momentum=0.1, eps=1e-5):
+def train_step(sd_np, x, x1, masks, targets, in_len, tgt_len, p_drop, momentum=0.1, eps=1e-5, dtype=torch.float32):
     """Returns (logp [T',B,C], loss, {key: grad}, {running-stat key: updated value}).  masks: list of arrays in the reference's
-    layouts: [B,ch,T,W1], [B,ch,T',W2], then [T',B,2H] per BatchRNN layer."""
-    sd = {k: torch.tensor(v, dtype=torch.float32) for k, v in sd_np.items() if np.asarray(v).dtype.kind == "f"}
+    layouts: [B,ch,T,W1], [B,ch,T',W2], then [T',B,2H] per BatchRNN layer.  dtype=torch.float64 runs the same graph in double: the
+    yardstick for how far two correct fp32 evaluations may differ on an ill-conditioned gradient (tests)."""
+    sd = {k: torch.tensor(v, dtype=dtype) for k, v in sd_np.items() if np.asarray(v).dtype.kind == "f"}
     params = {k: v.requires_grad_(True) for k, v in sd.items() if "running_" not in k}
     run = {k: v.clone() for k, v in sd.items() if "running_" in k}
     scale = 1.0 / (1.0 - p_drop)
@@ -145,7 +146,7 @@ def train_step(sd_np, x, x1, masks, targets, in_len, tgt_len, p_drop, momentum=0
                             training=True, momentum=momentum, eps=eps)
 
     def drop(t, m):
-        return t * (torch.as_tensor(m, dtype=torch.float32) * scale) if p_drop > 0 else t
+        return t * (torch.as_tensor(m, dtype=dtype) * scale) if p_drop > 0 else t
 
     def bilstm(t, prefix, bias, batch_first=False):
         H = params[prefix + ".weight_hh_l0"].shape[1]
@@ -155,7 +156,7 @@ def train_step(sd_np, x, x1, masks, targets, in_len, tgt_len, p_drop, momentum=0
         out, _, _ = torch._VF.lstm(t, (h0, h0.clone()), flat, bias, 1, 0.0, True, True, batch_first)
         return out
 
-    a = torch.as_tensor(x, dtype=torch.float32).unsqueeze(1)
+    a = torch.as_tensor(x, dtype=dtype).unsqueeze(1)
     for n, stride in ((0, (1, 2)), (1, (2, 2))):
         a = F.conv2d(a, params["conv.%d.conv.weight" % n], params["conv.%d.conv.bias" % n], stride=stride, padding=(1, 1))
         a = drop(F.relu(bn(a, "conv.%d.batch_norm" % n)), masks[n])

@@ -726,6 +726,43 @@ def test_train_step_against_torch_restatement(H, B, T, L):
             np.testing.assert_allclose(b_.cpu().numpy(), run[k], rtol=0, atol=1e-5, err_msg=k)
 
 
+def test_train_step_split_bf16_variant():
+    """The flagged variant of the training step (model.train_precision = "bf16x3": input projections, dX and dW_ih through the
+    split-bf16 x3 matrix-core GEMM, the weight gradients with the row axis cut into partial products) at a size where every one of
+    those paths is taken (B=32, T=160: 2560 rows), beside the exact mode, both against the restatement run in DOUBLE (at this size
+    torch's own fp32 evaluation is 5e-5..9e-5 of scale away from double, so it is no yardstick).
+    Exact mode: log-probs 1e-4, every gradient outside the CNN within 2e-5 of its scale (measured 7e-6).
+    Variant (operands carry 16 mantissa bits): log-probs 5e-4 (logits of magnitude ~16 after four layers), gradients 2e-4 of scale.
+    The CNN's gradients (conv.*) are sums over 2e7 ReLU gates, a handful of which sit within one rounding of zero: one gate flipping
+    moves those sums by 2e-4..1e-3 of scale (the restatement's own fp32 result moves by 1.7e-4 under a 1-ulp change of the input,
+    this path's by 2.4e-4), so for them the bound is 3e-3 in both modes.  The two modes must not be bit-identical."""
+    from oracle import ref_port
+    from ctc_attention_mispronunciation_amd.train import CTCLoss
+    geom = synth.Geometry(**synth.REFERENCE)
+    B, T, L = 32, 160, 12
+    sd, x, x1, masks, tg, il, tl = synth.train_case(geom, 77, B, T, L, 6)
+    logp, loss, grads, run = ref_port.train_step(sd, x, x1, masks, tg, il, tl, 0.2, dtype=torch.float64)
+    got = {}
+    for mode, tol_logp, tol_loss, tol_grad in (("bf16x3", 5e-4, 1e-4, 2e-4), ("f32", TOL, 1e-5, 2e-5)):
+        model = _train_model(geom, sd)
+        model.train_precision = mode
+        model._dropout_masks = [torch.from_numpy(m) for m in masks]
+        out = model(_cuda(x), _cuda(x1))
+        print(mode, "max |dlogp|", float(np.abs(out.detach().cpu().numpy() - logp).max()))
+        np.testing.assert_allclose(out.detach().cpu().numpy(), logp, rtol=0, atol=tol_logp, err_msg=mode)
+        l2 = CTCLoss(reduction="sum")(out, torch.from_numpy(tg), torch.from_numpy(il), torch.from_numpy(tl)) / B
+        assert abs(float(l2.detach()) - loss) <= tol_loss * abs(loss), mode
+        l2.backward()
+        errs = sorted(((float(np.abs(p_.grad.cpu().numpy() - grads[k]).max()) / max(1.0, float(np.abs(grads[k]).max())), k)
+                       for k, p_ in model.named_parameters() if not k.endswith("conv.bias")), reverse=True)
+        print(mode, "grad err / scale, largest:", [(k, "%.1e" % e) for e, k in errs[:6]])
+        for e, k in errs:
+            assert e <= (3e-3 if k.startswith("conv.") else tol_grad), (mode, k, e)
+        got[mode] = {k: p_.grad.clone() for k, p_ in model.named_parameters()}
+    k = "rnns.1.rnn.weight_ih_l0"
+    assert not torch.equal(got["f32"][k], got["bf16x3"][k])
+
+
 def test_ctc_loss_module_matches_nn_ctcloss():
     """The nn.CTCLoss-shaped callable (train_ctc.py:72,186): value and autograd gradient against the G5 goldens (torch's
     CTCLoss(sum) + backward), then 'mean' / 'none', 1-D concatenated targets and zero_infinity against torch on the CPU."""
