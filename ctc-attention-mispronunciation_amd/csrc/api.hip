@@ -302,11 +302,11 @@ static int run_stage(mdd_model *m, int si, const float *x, int B, int T, const i
 
 // Enter / leave the device gate around the enqueue of one forward on `st` (no-op while `st` is being captured by the
 // caller: the captured graph then carries the caller's own ordering).
-static int gate_enter(mdd_model *m, hipStream_t st, bool *held) {
+int device_gate_enter(int device, hipStream_t st, bool *held) {
     *held = false;
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     if (st && hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) return MDD_OK;
-    DeviceGate &g = g_gate[m->device & 63];
+    DeviceGate &g = g_gate[device & 63];
     g.mu.lock();
     *held = true;
     if (g.armed && g.stream != st) {
@@ -315,9 +315,9 @@ static int gate_enter(mdd_model *m, hipStream_t st, bool *held) {
     }
     return MDD_OK;
 }
-static int gate_leave(mdd_model *m, hipStream_t st, bool held, int rc) {
+int device_gate_leave(int device, hipStream_t st, bool held, int rc) {
     if (!held) return rc;
-    DeviceGate &g = g_gate[m->device & 63];
+    DeviceGate &g = g_gate[device & 63];
     hipError_t e = hipSuccess;
     if (!g.done) e = hipEventCreateWithFlags(&g.done, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventRecord(g.done, st);
@@ -326,6 +326,8 @@ static int gate_leave(mdd_model *m, hipStream_t st, bool held, int rc) {
     if (e != hipSuccess && rc == MDD_OK) { set_error("device gate: %s", hipGetErrorString(e)); return MDD_ERR_HIP; }
     return rc;
 }
+static int gate_enter(mdd_model *m, hipStream_t st, bool *held) { return device_gate_enter(m->device, st, held); }
+static int gate_leave(mdd_model *m, hipStream_t st, bool held, int rc) { return device_gate_leave(m->device, st, held, rc); }
 
 static int forward_enqueue(mdd_model *m, const float *x, int B, int T, const int64_t *x1, int L, float *logp, hipStream_t st) {
     for (int si = 0; si < n_stages(m); si++)

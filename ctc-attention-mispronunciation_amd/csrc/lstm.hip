@@ -333,6 +333,7 @@ struct PersistArgs {
     int T, B, BG, BGr;               // BG: padded rows per group (multiple of 16), BGr: real rows per group
     long long *dbg;                  // diagnostic builds only: per-workgroup cycle sums of the step phases (null in production)
     const int *seqlen;               // see LstmStepArgs::seqlen (null = every row runs all T steps)
+    float *gates_save, *c_save;      // TRAIN instantiations: post-activation i,f,g,o [T][B][2][H][4] and c_t [T][B][2][H] for the backward pass
     int early;                       // diagnostic (MDD_LSTM_EARLY): request the next tile's panel a whole MFMA section too early, so that stale panels and the redo path occur
 };
 
@@ -412,7 +413,7 @@ __device__ __forceinline__ void lds_dma16(const void *g, void *l) {
     else asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(g), "s"(la) : "memory", "m0");
 }
 
-template <int H, int NBT, int RTW>
+template <int H, int NBT, int RTW, bool TRAIN = false>
 __global__ __launch_bounds__(256, 1) void lstm_layer_granule_kernel(PersistArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int NTH = 256, KS = H / 32, RM = 4 * H / 8;
@@ -711,6 +712,15 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_granule_kernel(PersistArgs 
                 const float hr = og * fast_tanh(cn);
                 hn[rt] = (valid && live) ? hr : 0.f;
                 cst[rt][bt] = live ? cn : 0.f;
+                if (TRAIN) {   // what the backward step reads: the gates after their nonlinearities and c_t, in the training layout (one 64-byte run per row and quad)
+                    const unsigned el = valid ? (unsigned)(((g * a.BGr + lb) * 2 + d) * H + member * UW + (wave * RTW + rt) * 4 + kq) : 0x0fffffffu;
+                    const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(a.gates_save + (size_t)t * B * 2 * H * 4, 0, B * 2 * H * 16, 0x00020000);
+                    const __amdgpu_buffer_rsrc_t rc_ = __builtin_amdgcn_make_buffer_rsrc(a.c_save + (size_t)t * B * 2 * H, 0, B * 2 * H * 4, 0x00020000);
+                    u32x4 gq;
+                    gq[0] = __float_as_uint(ig); gq[1] = __float_as_uint(fg); gq[2] = __float_as_uint(cg); gq[3] = __float_as_uint(og);
+                    __builtin_amdgcn_raw_buffer_store_b128(gq, rg, el * 16u, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(cn), rc_, el * 4u, 0, 0);
+                }
             }
 #pragma unroll
             for (int rt = 0; rt < RTW; rt++) {
@@ -728,7 +738,7 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_granule_kernel(PersistArgs 
             PSTAMP(3);
             // ---- publish h_s (no drain, no signal): the workgroup's share of the tile's panel is one contiguous run of
             // 16 * UW / 4 chunks, written as 16-byte write-through stores straight from the Og tile (same order)
-            younger = early_gx; early_gx = 0;
+            younger = early_gx + (TRAIN ? 2 * RTW : 0); early_gx = 0;   // (TRAIN: the cell update's stores are younger than the sweep request too)
             {
                 const bool pub = s + 1 < T, defer = PF == 0 && s > 0 && s + 1 < T;
                 const u32x4 pv = *reinterpret_cast<const u32x4 *>(Og + qp * 4);
@@ -759,12 +769,12 @@ int granule_bg(int B) { const int r = (B + 15) / 16; return (r + 15) / 16 * 16; 
 
 static constexpr int kPersistGrid = 256;   // see persistent_grid_fits()
 
-template <int H, int NBT, int RTW>
+template <int H, int NBT, int RTW, bool TRAIN = false>
 static int launch_granule_t(PersistArgs a, hipStream_t st) {
     const size_t smem = (size_t)16 * (H / 8) * 12 + (size_t)NBT * 2 * 16 * (H / 8) * 16 + (size_t)2 * 16 * H * 4;   // tiles (2 bf16 planes, fp32, tagged words) + gx slabs (2 parities) + two panel buffers
     MDD_HIP_CHECK(hipMemsetAsync(a.sync, 0, 32 * sizeof(unsigned int), st));
     MDD_HIP_CHECK(hipMemsetAsync(a.hx, 0, (size_t)2 * 32 * NBT * 16 * H * 4, st));   // tags must start at 0 on every launch
-    hipLaunchKernelGGL((lstm_layer_granule_kernel<H, NBT, RTW>), dim3(kPersistGrid), dim3(256), smem, st, a);
+    hipLaunchKernelGGL((lstm_layer_granule_kernel<H, NBT, RTW, TRAIN>), dim3(kPersistGrid), dim3(256), smem, st, a);
     MDD_LAUNCH_CHECK();
     return MDD_OK;
 }
@@ -778,7 +788,17 @@ int launch_lstm_layer_granule(const LstmStepArgs &s, unsigned short *hx, unsigne
     a.early = getenv("MDD_LSTM_EARLY") != nullptr;
     if (a.oscale == nullptr) a.oshift = nullptr;
     if (a.out && a.out != a.out_raw) { set_error("granule lstm: a separate scaled fp32 output is not supported (split planes carry it)"); return MDD_ERR_ARG; }
+    a.gates_save = s.gates_save; a.c_save = s.c_save;
     const int nbt = a.BG / 16;
+    if (s.gates_save) {   // training forward: gates and cell states are saved for the backward pass (B <= 512)
+        if (!s.c_save || a.seqlen || (size_t)s.B * 2 * s.H * 16 > 0x7fffffffu) { set_error("granule lstm (train): bad arguments"); return MDD_ERR_ARG; }
+        if (s.H == 384 && nbt == 1) return launch_granule_t<384, 1, 3, true>(a, st);
+        if (s.H == 384 && nbt == 2) return launch_granule_t<384, 2, 3, true>(a, st);
+        if (s.H == 256 && nbt == 1) return launch_granule_t<256, 1, 2, true>(a, st);
+        if (s.H == 256 && nbt == 2) return launch_granule_t<256, 2, 2, true>(a, st);
+        set_error("granule lstm (train): built for H in {256,384}, B <= 512 (H=%d B=%d)", s.H, s.B);
+        return MDD_ERR_ARG;
+    }
     if (nbt < 1 || nbt > 4) { set_error("granule lstm: B=%d needs %d row tiles per team (max 4)", s.B, nbt); return MDD_ERR_ARG; }
     if (s.H == 384) return nbt == 1 ? launch_granule_t<384, 1, 3>(a, st) : nbt == 2 ? launch_granule_t<384, 2, 3>(a, st)
                          : nbt == 3 ? launch_granule_t<384, 3, 3>(a, st) : launch_granule_t<384, 4, 3>(a, st);
@@ -791,6 +811,9 @@ int launch_lstm_layer_granule(const LstmStepArgs &s, unsigned short *hx, unsigne
 int init_granule_attributes() {
 #define GATTR(H, N, R) MDD_HIP_CHECK(hipFuncSetAttribute((const void *)lstm_layer_granule_kernel<H, N, R>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024))
     GATTR(384, 1, 3); GATTR(384, 2, 3); GATTR(384, 3, 3); GATTR(384, 4, 3); GATTR(256, 1, 2); GATTR(256, 2, 2); GATTR(256, 3, 2); GATTR(256, 4, 2);
+#undef GATTR
+#define GATTR(H, N, R) MDD_HIP_CHECK(hipFuncSetAttribute((const void *)lstm_layer_granule_kernel<H, N, R, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024))
+    GATTR(384, 1, 3); GATTR(384, 2, 3); GATTR(256, 1, 2); GATTR(256, 2, 2);
 #undef GATTR
     return MDD_OK;
 }

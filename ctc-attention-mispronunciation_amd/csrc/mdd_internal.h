@@ -97,5 +97,9 @@ int init_granule_attributes();
 int persistent_grid_fits(int n_cu);   // 1 when all 256 workgroups of a persistent layer launch can be resident at once
 // data-tagged variant (8-workgroup teams, no counter): hx = 2*32*granule_bg(B)*H u64 granules (+ stamps), sync: 32 uints
 int launch_lstm_layer_granule(const LstmStepArgs &s, unsigned short *hx, unsigned int *sync, int *err_flag, hipStream_t st);
+// Per-device ticket around work that contains persistent launches (api.hip): launches of different handles / streams of one device run
+// one after another on the GPU (event dependency; the host does not block).  enter locks, leave records the event and unlocks.
+int device_gate_enter(int device, hipStream_t st, bool *held);
+int device_gate_leave(int device, hipStream_t st, bool held, int rc);
 
 }  // namespace mdd

@@ -48,6 +48,9 @@ struct mdd_train_ws {
     std::vector<mdd::Buf> xin, hraw, pd, gates, cst, wihp, whhp, whht;    // per rnn layer (index layers = the text encoder)
     mdd::Buf tbias;
     mdd::Buf d_a, d_b, d_c, part, dtext, dkey;      // backward temporaries
+    mdd::Buf whhs, hx;                 // flagged variant: W_hh' as hi/lo planes and the h exchange buffer of the persistent layer kernel
+    unsigned int *sync_words = nullptr;
+    bool persist_ok = false;           // the device can hold the persistent layer kernel's grid
     mdd::Buf xs_a, xs_b;               // split-bf16 operand planes of the flagged variant's GEMMs (hi plane, then lo plane)
     int precision = 0;                 // 0: exact fp32 MFMA everywhere (the reference trains in fp32); 1: the large contractions as split-bf16 x3
     int *err_flag = nullptr;           // set by the embedding gather on an id outside the table
@@ -58,11 +61,12 @@ struct mdd_train_ws {
     const float *x = nullptr;
     ~mdd_train_ws() {
         mdd::Buf *all[] = {&z0, &a0, &col1, &w1r, &z1, &a1, &seq0, &gx, &dgx, &hb, &cb, &emb, &text, &key, &att, &cat, &ycat, &logits, &logp, &stats,
-                           &tbias, &d_a, &d_b, &d_c, &part, &masks, &dtext, &dkey, &xs_a, &xs_b};
+                           &tbias, &d_a, &d_b, &d_c, &part, &masks, &dtext, &dkey, &xs_a, &xs_b, &whhs, &hx};
         for (auto *b : all) b->release();
         for (auto *v : {&xin, &hraw, &pd, &gates, &cst, &wihp, &whhp, &whht}) for (auto &b : *v) b.release();
         if (dacc) (void)hipFree(dacc);
         if (err_flag) (void)hipFree(err_flag);
+        if (sync_words) (void)hipFree(sync_words);
     }
 };
 
@@ -146,6 +150,25 @@ static int gemm_big(mdd_train_ws *w, bool ta, bool tb, const float *A, int lda, 
     return launch_reduce_parts(w->part.p, S, (size_t)M * N, C, st);
 }
 
+
+// One bidirectional layer of the training forward (gates and cell states saved for the backward pass).  Exact mode: one launch per
+// step, fp32 MFMA.  Flagged split-bf16 variant on a device that holds the persistent grid: the decode path's layer kernel (one
+// launch, W_hh' resident in registers as bf16 hi/lo fragments, h exchanged inside 8-workgroup teams) with the saves added.
+static int lstm_forward_layer(mdd_train_ws *w, LstmStepArgs &a, hipStream_t st) {
+    const int H = a.H;
+    if (w->precision == 1 && w->persist_ok && (H == 384 || H == 256) && a.B <= 512) {
+        const size_t nW = (size_t)8 * H * H;
+        if (int rc = w->whhs.need(nW)) return rc;
+        unsigned short *hi = reinterpret_cast<unsigned short *>(w->whhs.p), *lo = hi + nW;
+        if (int rc = launch_split_rows(a.whh, H, (size_t)8 * H, H, H, hi, lo, st)) return rc;
+        a.whh_split = SplitPtr{hi, lo};
+        a.out = nullptr;
+        if (int rc = w->hx.need((size_t)2 * 32 * granule_bg(a.B) * H * 2 + 64 + 256 * 6 * 2)) return rc;
+        return launch_lstm_layer_granule(a, reinterpret_cast<unsigned short *>(w->hx.p), w->sync_words, w->err_flag + 1, st);
+    }
+    return launch_lstm_layer_train(a, st);
+}
+
 }  // namespace mdd
 
 using namespace mdd;
@@ -168,8 +191,14 @@ extern "C" int mdd_train_create(const mdd_config *cfg, int device, mdd_train_ws 
     build_info(w);
     const int nl = cfg->layers + 1;
     w->xin.resize(nl); w->hraw.resize(nl); w->pd.resize(nl); w->gates.resize(nl); w->cst.resize(nl); w->wihp.resize(nl); w->whhp.resize(nl); w->whht.resize(nl);
-    if (hipMalloc((void **)&w->dacc, sizeof(double) * 2 * 8192) != hipSuccess || hipMalloc((void **)&w->err_flag, sizeof(int)) != hipSuccess ||
-        hipMemset(w->err_flag, 0, sizeof(int)) != hipSuccess) { delete w; set_error("mdd_train_create: out of memory"); return MDD_ERR_NOMEM; }
+    if (hipMalloc((void **)&w->dacc, sizeof(double) * 2 * 8192) != hipSuccess || hipMalloc((void **)&w->err_flag, 2 * sizeof(int)) != hipSuccess ||
+        hipMemset(w->err_flag, 0, 2 * sizeof(int)) != hipSuccess || hipMalloc((void **)&w->sync_words, 32 * sizeof(unsigned int)) != hipSuccess) {
+        delete w; set_error("mdd_train_create: out of memory"); return MDD_ERR_NOMEM;
+    }
+    if (int rc = init_gemm_attributes()) { delete w; return rc; }
+    if (int rc = init_granule_attributes()) { delete w; return rc; }
+    { int n_cu = 0; w->persist_ok = hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && persistent_grid_fits(n_cu) &&
+                                     !(getenv("MDD_LSTM") && !strcmp(getenv("MDD_LSTM"), "step")); }
     if (8 * cfg->hidden > 8192) { delete w; set_error("mdd_train_create: hidden too large for the statistics scratch"); return MDD_ERR_ARG; }
     *out = w;
     return MDD_OK;
@@ -196,7 +225,18 @@ extern "C" int64_t mdd_train_mask_bytes(mdd_train_ws *w, int32_t site, int32_t B
 #define P(key) (tensors[idx(w, key)])
 #define TRY(expr) do { if (int rc_ = (expr)) return rc_; } while (0)
 
+static int train_forward_enqueue(mdd_train_ws *w, float *const *tensors, const float *x_dev, int32_t B, int32_t T, const int64_t *x1_dev, int32_t L,
+                                 const uint8_t *const *masks, uint64_t seed, float p_drop, float *logp_dev, void *stream);
 extern "C" int mdd_train_forward(mdd_train_ws *w, float *const *tensors, const float *x_dev, int32_t B, int32_t T, const int64_t *x1_dev, int32_t L,
+                                 const uint8_t *const *masks, uint64_t seed, float p_drop, float *logp_dev, void *stream) {
+    if (!w) { set_error("mdd_train_forward: null handle"); return MDD_ERR_ARG; }
+    const bool gated = w->precision == 1 && w->persist_ok;      // the forward then contains persistent launches: one at a time per device
+    bool held = false;
+    if (gated) { MDD_HIP_CHECK(hipSetDevice(w->device)); if (int rc = device_gate_enter(w->device, (hipStream_t)stream, &held)) return rc; }
+    const int rc = train_forward_enqueue(w, tensors, x_dev, B, T, x1_dev, L, masks, seed, p_drop, logp_dev, stream);
+    return gated ? device_gate_leave(w->device, (hipStream_t)stream, held, rc) : rc;
+}
+static int train_forward_enqueue(mdd_train_ws *w, float *const *tensors, const float *x_dev, int32_t B, int32_t T, const int64_t *x1_dev, int32_t L,
                                  const uint8_t *const *masks, uint64_t seed, float p_drop, float *logp_dev, void *stream) {
     if (!w || !tensors || !x_dev || !x1_dev || !logp_dev || B <= 0 || T < 2 || (T & 1) || L <= 0 || p_drop < 0.f || p_drop >= 1.f) {
         set_error("mdd_train_forward: bad argument"); return MDD_ERR_ARG;
@@ -272,7 +312,7 @@ extern "C" int mdd_train_forward(mdd_train_ws *w, float *const *tensors, const f
         a.gx = w->gx.p; a.whh = w->whhp[n].p; a.hbuf = w->hb.p; a.cbuf = w->cb.p; a.out = w->hraw[n].p; a.out_raw = w->hraw[n].p;
         a.out_split = SplitPtr{nullptr, nullptr}; a.oscale = nullptr; a.oshift = nullptr; a.T = Tp; a.B = B; a.H = H;
         a.whh_split = SplitPtr{nullptr, nullptr}; a.hsplit = nullptr; a.packed = 0; a.gates_save = w->gates[n].p; a.c_save = w->cst[n].p;
-        TRY(launch_lstm_layer_train(a, st));
+        TRY(lstm_forward_layer(w, a, st));
         TRY(launch_dropout_rows(w->hraw[n].p, w->mask_ptr[2 + n], scale, R * H2, w->pd[n].p, st));
     }
     const float *X = w->pd[nl - 1].p;
@@ -290,7 +330,7 @@ extern "C" int mdd_train_forward(mdd_train_ws *w, float *const *tensors, const f
         a.gx = w->gx.p; a.whh = w->whhp[nl].p; a.hbuf = w->hb.p; a.cbuf = w->cb.p; a.out = w->hraw[nl].p; a.out_raw = w->hraw[nl].p;
         a.out_split = SplitPtr{nullptr, nullptr}; a.oscale = nullptr; a.oshift = nullptr; a.T = L; a.B = B; a.H = H;
         a.whh_split = SplitPtr{nullptr, nullptr}; a.hsplit = nullptr; a.packed = 0; a.gates_save = w->gates[nl].p; a.c_save = w->cst[nl].p;
-        TRY(launch_lstm_layer_train(a, st));
+        TRY(lstm_forward_layer(w, a, st));
     }
     TRY(launch_gemm_f32(false, false, w->hraw[nl].p, P("score.weight"), nullptr, w->key.p, (int)Rt, H2, H2, H2, H2, H2, 1, 0, 0, 0, false, st));
     // ---- attention: S = X.key^T, softmax over L (no scale, no mask), ctx = A.text, cat(X, ctx)
@@ -420,9 +460,11 @@ extern "C" int mdd_train_backward(mdd_train_ws *w, float *const *tensors, const 
 extern "C" int mdd_train_sync(mdd_train_ws *w, void *stream) {
     if (!w) { set_error("null handle"); return MDD_ERR_ARG; }
     MDD_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
-    int flag = 0;
-    MDD_HIP_CHECK(hipMemcpy(&flag, w->err_flag, sizeof(int), hipMemcpyDeviceToHost));
-    if (flag) { MDD_HIP_CHECK(hipMemset(w->err_flag, 0, sizeof(int))); set_error("index out of range in self"); return MDD_ERR_ARG; }
+    int flag[2] = {0, 0};
+    MDD_HIP_CHECK(hipMemcpy(flag, w->err_flag, 2 * sizeof(int), hipMemcpyDeviceToHost));
+    if (flag[0] || flag[1]) MDD_HIP_CHECK(hipMemset(w->err_flag, 0, 2 * sizeof(int)));
+    if (flag[1]) { set_error("persistent BiLSTM layer kernel gave up waiting for its team (was another persistent launch resident on this device?)"); return MDD_ERR_HIP; }
+    if (flag[0]) { set_error("index out of range in self"); return MDD_ERR_ARG; }
     return MDD_OK;
 }
 

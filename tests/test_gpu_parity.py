@@ -726,10 +726,12 @@ def test_train_step_against_torch_restatement(H, B, T, L):
             np.testing.assert_allclose(b_.cpu().numpy(), run[k], rtol=0, atol=1e-5, err_msg=k)
 
 
-def test_train_step_split_bf16_variant():
+@pytest.mark.parametrize("H,B,T,L", [(384, 32, 160, 12), (256, 272, 16, 5)])
+def test_train_step_split_bf16_variant(H, B, T, L):
     """The flagged variant of the training step (model.train_precision = "bf16x3": input projections, dX and dW_ih through the
-    split-bf16 x3 matrix-core GEMM, the weight gradients with the row axis cut into partial products) at a size where every one of
-    those paths is taken (B=32, T=160: 2560 rows), beside the exact mode, both against the restatement run in DOUBLE (at this size
+    split-bf16 x3 matrix-core GEMM, the weight gradients with the row axis cut into partial products, the forward recurrences in the
+    persistent layer kernel with h carried as bf16 hi/lo) at sizes where every one of those paths is taken (B=32, T=160: 2560 rows,
+    one batch tile per team; B=272, H=256: two tiles per team), beside the exact mode, both against the restatement run in DOUBLE (at this size
     torch's own fp32 evaluation is 5e-5..9e-5 of scale away from double, so it is no yardstick).
     Exact mode: log-probs 1e-4, every gradient outside the CNN within 2e-5 of its scale (measured 7e-6).
     Variant (operands carry 16 mantissa bits): log-probs 5e-4 (logits of magnitude ~16 after four layers), gradients 2e-4 of scale.
@@ -738,9 +740,8 @@ def test_train_step_split_bf16_variant():
     this path's by 2.4e-4), so for them the bound is 3e-3 in both modes.  The two modes must not be bit-identical."""
     from oracle import ref_port
     from ctc_attention_mispronunciation_amd.train import CTCLoss
-    geom = synth.Geometry(**synth.REFERENCE)
-    B, T, L = 32, 160, 12
-    sd, x, x1, masks, tg, il, tl = synth.train_case(geom, 77, B, T, L, 6)
+    geom = synth.Geometry(**dict(synth.REFERENCE, hidden=H))
+    sd, x, x1, masks, tg, il, tl = synth.train_case(geom, 77, B, T, L, min(6, T // 4))
     logp, loss, grads, run = ref_port.train_step(sd, x, x1, masks, tg, il, tl, 0.2, dtype=torch.float64)
     got = {}
     for mode, tol_logp, tol_loss, tol_grad in (("bf16x3", 5e-4, 1e-4, 2e-4), ("f32", TOL, 1e-5, 2e-5)):
