@@ -6,9 +6,10 @@
 
 namespace mdd {
 
-struct BnSite {            // how to find the dropout byte of element (row, f): conv sites only (mask in [B,ch,T,W] order)
-    const unsigned char *mask; int T, W; float scale;
+struct BnSite {            // ReLU + dropout behind a BatchNorm (the conv sites): the dropout byte of element (row, f) is mask[row * F + f]
+    const unsigned char *mask; float scale;                // (channels-last copy of the [B,ch,T,W] mask: launch_mask_rows); null = no dropout
 };
+int launch_mask_rows(const unsigned char *src, unsigned char *dst, int B, int F, int TW, hipStream_t st);
 
 struct LstmBwdArgs {
     const float *dout;     // [T][B][2H]   gradient arriving at the layer's output h

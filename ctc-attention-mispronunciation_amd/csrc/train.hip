@@ -56,12 +56,14 @@ struct mdd_train_ws {
     int *err_flag = nullptr;           // set by the embedding gather on an id outside the table
     mdd::Buf masks;                    // generated dropout masks (bytes)
     std::vector<const unsigned char *> mask_ptr;
+    const unsigned char *mask_rows[2] = {nullptr, nullptr};   // the two conv sites' masks in channels-last order
+    mdd::Buf maskt;
     double *dacc = nullptr;            // fp64 column sums
     const int64_t *ids = nullptr;      // canonical ids of the saved forward (caller memory, must stay valid until backward)
     const float *x = nullptr;
     ~mdd_train_ws() {
         mdd::Buf *all[] = {&z0, &a0, &col1, &w1r, &z1, &a1, &seq0, &gx, &dgx, &hb, &cb, &emb, &text, &key, &att, &cat, &ycat, &logits, &logp, &stats,
-                           &tbias, &d_a, &d_b, &d_c, &part, &masks, &dtext, &dkey, &xs_a, &xs_b, &whhs, &hx};
+                           &tbias, &d_a, &d_b, &d_c, &part, &masks, &dtext, &dkey, &xs_a, &xs_b, &whhs, &hx, &maskt};
         for (auto *b : all) b->release();
         for (auto *v : {&xin, &hraw, &pd, &gates, &cst, &wihp, &whhp, &whht}) for (auto &b : *v) b.release();
         if (dacc) (void)hipFree(dacc);
@@ -281,17 +283,26 @@ static int train_forward_enqueue(mdd_train_ws *w, float *const *tensors, const f
             }
         }
     }
+    w->mask_rows[0] = w->mask_rows[1] = nullptr;
+    if (p_drop > 0.f) {   // the conv sites' kernels walk channels-last rows: their masks once in that order
+        const size_t n0 = (R0 * ch + 15) & ~(size_t)15, n1 = R1 * ch;
+        TRY(w->maskt.need((n0 + n1 + 3) / 4));
+        unsigned char *m0 = reinterpret_cast<unsigned char *>(w->maskt.p), *m1 = m0 + n0;
+        TRY(launch_mask_rows(w->mask_ptr[0], m0, B, ch, T * W1, st));
+        TRY(launch_mask_rows(w->mask_ptr[1], m1, B, ch, Tp * W2, st));
+        w->mask_rows[0] = m0; w->mask_rows[1] = m1;
+    }
     float *mean = w->stats.p, *invstd = w->stats.p + (2 * ch + nl * H2 + 2 * H2);
     // ---- conv0 -> BN -> ReLU -> Dropout
     TRY(launch_conv0_train_fwd(x_dev, P("conv.0.conv.weight"), P("conv.0.conv.bias"), w->z0.p, B, T, c.feat, ch, st));
-    BnSite s0{w->mask_ptr[0], T, W1, scale};
+    BnSite s0{w->mask_rows[0], scale};
     TRY(launch_bn_train_fwd(w->z0.p, R0, ch, P("conv.0.batch_norm.weight"), P("conv.0.batch_norm.bias"), eps, mom, P("conv.0.batch_norm.running_mean"),
                             P("conv.0.batch_norm.running_var"), w->dacc, mean, invstd, &s0, w->a0.p, st));
     // ---- conv1 (im2col + GEMM) -> BN -> ReLU -> Dropout -> [T',B,ch*W2]
     TRY(launch_im2col1(w->a0.p, w->col1.p, B, T, W1, W2, ch, st));
     TRY(launch_pack_w1(P("conv.1.conv.weight"), w->w1r.p, ch, true, st));
     TRY(launch_gemm_f32(false, false, w->col1.p, w->w1r.p, P("conv.1.conv.bias"), w->z1.p, (int)R1, ch, 9 * ch, 9 * ch, 9 * ch, ch, 1, 0, 0, 0, false, st));
-    BnSite s1{w->mask_ptr[1], Tp, W2, scale};
+    BnSite s1{w->mask_rows[1], scale};
     TRY(launch_bn_train_fwd(w->z1.p, R1, ch, P("conv.1.batch_norm.weight"), P("conv.1.batch_norm.bias"), eps, mom, P("conv.1.batch_norm.running_mean"),
                             P("conv.1.batch_norm.running_var"), w->dacc, mean + ch, invstd + ch, &s1, w->a1.p, st));
     TRY(launch_cnn_seq(w->a1.p, w->seq0.p, B, Tp, W2, ch, true, st));
@@ -436,7 +447,7 @@ extern "C" int mdd_train_backward(mdd_train_ws *w, float *const *tensors, const 
     // ---- conv1: relayout, BN/ReLU/Dropout, weight and input gradients
     float *da1 = w->a1.p;                                           // a1 is not needed again
     TRY(launch_cnn_seq(da1, w->d_c.p, B, Tp, W2, ch, false, st));
-    BnSite s1{w->mask_ptr[1], Tp, W2, scale};
+    BnSite s1{w->mask_rows[1], scale};
     float *dz1 = w->d_a.p;
     TRY(launch_bn_train_bwd(w->z1.p, da1, R1, ch, P("conv.1.batch_norm.weight"), P("conv.1.batch_norm.bias"), mean + ch, invstd + ch, &s1, w->dacc, dz1,
                             GR("conv.1.batch_norm.weight"), GR("conv.1.batch_norm.bias"), st));
@@ -448,7 +459,7 @@ extern "C" int mdd_train_backward(mdd_train_ws *w, float *const *tensors, const 
     float *da0 = w->d_c.p;
     TRY(launch_col2im1(w->col1.p, da0, B, T, W1, W2, ch, st));
     // ---- conv0
-    BnSite s0{w->mask_ptr[0], T, W1, scale};
+    BnSite s0{w->mask_rows[0], scale};
     float *dz0 = w->d_a.p;
     TRY(launch_bn_train_bwd(w->z0.p, da0, R0, ch, P("conv.0.batch_norm.weight"), P("conv.0.batch_norm.bias"), mean, invstd, &s0, w->dacc, dz0,
                             GR("conv.0.batch_norm.weight"), GR("conv.0.batch_norm.bias"), st));

@@ -72,33 +72,42 @@ int launch_conv0_train_fwd(const float *x, const float *w, const float *bias, fl
 // fp64 atomic per (workgroup, entry): the order of the adds moves the result by ~1e-16 relative, far below fp32 rounding.
 template <int CH>
 __global__ __launch_bounds__(256) void conv0_train_bwd_kernel(const float *__restrict__ x, const float *__restrict__ dz, double *__restrict__ acc /*[CH*10]*/,
-                                                              int B, int T, int F, int W1, int pos_per_wg) {
+                                                              int B, int T, int F, int W1, int rows_per_wave) {
+    // A wave walks whole (b, t) rows of W1 output positions.  lane = (position slot, channel): the CH lanes of a slot read one contiguous
+    // dz row and the same nine input samples (broadcast); a lane keeps its channel's nine tap sums and the bias sum (k = 9) in registers
+    // (rows_per_wave * W1 * CH / 64 terms in fp32), then fp64 across workgroups.
+    constexpr int PPW = 64 / CH;
     __shared__ float part[4][CH * 10];
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const size_t npos = (size_t)B * T * W1, p0 = (size_t)blockIdx.x * pos_per_wg;
-    // a lane owns entries e = lane, lane + 64, ... of the CH x 10 table (k = 9 is the bias column); it walks the positions of its wave
-    constexpr int NE = (CH * 10 + 63) / 64;
-    float sum[NE];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, c = lane % CH, slot = lane / CH;
+    const int nrow = B * T, row0 = (blockIdx.x * 4 + wave) * rows_per_wave;
+    float sum[10];
 #pragma unroll
-    for (int i = 0; i < NE; i++) sum[i] = 0.f;
-    for (size_t pos = p0 + wave; pos < p0 + pos_per_wg && pos < npos; pos += 4) {
-        const int wo = (int)(pos % W1), t = (int)((pos / W1) % T), b = (int)(pos / ((size_t)W1 * T));
+    for (int k = 0; k < 10; k++) sum[k] = 0.f;
+    for (int row = row0; row < min(row0 + rows_per_wave, nrow); row++) {
+        const int t = row % T;
+        const float *xr = x + (size_t)row * F;                      // input row t of utterance b; rows t-1 / t+1 exist unless at the edge
+        const bool up = t > 0, dn = t + 1 < T;
+        const float *dzr = dz + (size_t)row * W1 * CH;
+        for (int wo = slot; wo < W1; wo += PPW) {
+            const float dzv = dzr[wo * CH + c];
 #pragma unroll
-        for (int i = 0; i < NE; i++) {
-            const int e = lane + i * 64;
-            if (e < CH * 10) {
-                const int c = e / 10, k = e - c * 10;
-                float pv = 1.f;
-                if (k < 9) {
-                    const int ti = t + k / 3 - 1, fi = wo * 2 + k % 3 - 1;
-                    pv = (ti >= 0 && ti < T && fi >= 0 && fi < F) ? x[((size_t)b * T + ti) * F + fi] : 0.f;
-                }
-                sum[i] = fmaf(dz[pos * CH + c], pv, sum[i]);
+            for (int kw = 0; kw < 3; kw++) {
+                const int fi = wo * 2 + kw - 1;
+                const bool in = fi >= 0 && fi < F;
+                const float p0 = (in && up) ? xr[fi - F] : 0.f, p1 = in ? xr[fi] : 0.f, p2 = (in && dn) ? xr[fi + F] : 0.f;
+                sum[kw] = fmaf(dzv, p0, sum[kw]); sum[3 + kw] = fmaf(dzv, p1, sum[3 + kw]); sum[6 + kw] = fmaf(dzv, p2, sum[6 + kw]);
             }
+            sum[9] += dzv;
         }
     }
 #pragma unroll
-    for (int i = 0; i < NE; i++) { const int e = lane + i * 64; if (e < CH * 10) part[wave][e] = sum[i]; }
+    for (int k = 0; k < 10; k++)
+#pragma unroll
+        for (int o = CH; o < 64; o <<= 1) sum[k] += __shfl_xor(sum[k], o);
+    if (lane < CH) {
+#pragma unroll
+        for (int k = 0; k < 10; k++) part[wave][c * 10 + k] = sum[k];
+    }
     __syncthreads();
     for (int e = tid; e < CH * 10; e += 256) atomicAdd(&acc[e], (double)((part[0][e] + part[1][e]) + (part[2][e] + part[3][e])));
 }
@@ -112,10 +121,11 @@ int launch_conv0_train_bwd(const float *x, const float *dz, double *acc, float *
     const int W1 = (F + 2 - 3) / 2 + 1;
     const size_t npos = (size_t)B * T * W1;
     MDD_HIP_CHECK(hipMemsetAsync(acc, 0, sizeof(double) * ch * 10, st));
-    const int per = 2048;
-    dim3 grid((unsigned)((npos + per - 1) / per)), block(256);
-    if (ch == 32) hipLaunchKernelGGL(conv0_train_bwd_kernel<32>, grid, block, 0, st, x, dz, acc, B, T, F, W1, per);
-    else if (ch == 4) hipLaunchKernelGGL(conv0_train_bwd_kernel<4>, grid, block, 0, st, x, dz, acc, B, T, F, W1, per);
+    (void)npos;
+    const int rpw = 4;                                             // (b, t) rows per wave: ~500 workgroups at B*T = 8000
+    dim3 grid((unsigned)((B * T + 4 * rpw - 1) / (4 * rpw))), block(256);
+    if (ch == 32) hipLaunchKernelGGL(conv0_train_bwd_kernel<32>, grid, block, 0, st, x, dz, acc, B, T, F, W1, rpw);
+    else if (ch == 4) hipLaunchKernelGGL(conv0_train_bwd_kernel<4>, grid, block, 0, st, x, dz, acc, B, T, F, W1, rpw);
     else { set_error("conv0 (train): channels=%d not built", ch); return MDD_ERR_ARG; }
     hipLaunchKernelGGL(conv0_bwd_finish_kernel, dim3((ch * 10 + 63) / 64), dim3(64), 0, st, acc, dw, db, ch);
     MDD_LAUNCH_CHECK();
@@ -125,31 +135,29 @@ int launch_conv0_train_bwd(const float *x, const float *dz, double *acc, float *
 // ------------------------------------------------------------------------------------------------ conv1 (ch -> ch, stride 2x2) as im2col + GEMM
 // col[(b,t',w'), (kh*3+kw)*ch + ci] = a0[b, 2t'+kh-1, 2w'+kw-1, ci]   (zero outside)
 __global__ void im2col1_kernel(const float *__restrict__ a0, float *__restrict__ col, int B, int T, int W1, int W2, int ch) {
-    const int Tp = T / 2, Kc = 9 * ch;
-    const size_t n = (size_t)B * Tp * W2 * 9;          // one thread per (position, tap): ch contiguous floats
+    const int Tp = T / 2, Kc = 9 * ch, c4n = ch / 4;
+    const size_t n = (size_t)B * Tp * W2 * 9 * c4n;    // one thread per 16 bytes of col, in col's own order: stores (and each tap's loads) are contiguous
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        const int tap = (int)(i % 9);
-        const size_t pos = i / 9;
+        const int c = (int)(i % c4n) * 4;
+        const size_t pt = i / c4n;
+        const int tap = (int)(pt % 9);
+        const size_t pos = pt / 9;
         const int wo = (int)(pos % W2), tp = (int)((pos / W2) % Tp), b = (int)(pos / ((size_t)W2 * Tp));
         const int ti = 2 * tp + tap / 3 - 1, wi = 2 * wo + tap % 3 - 1;
-        float *dst = col + pos * Kc + tap * ch;
-        if (ti >= 0 && ti < T && wi >= 0 && wi < W1) {
-            const float *src = a0 + (((size_t)b * T + ti) * W1 + wi) * ch;
-            for (int c = 0; c < ch; c += 4) *reinterpret_cast<float4 *>(dst + c) = *reinterpret_cast<const float4 *>(src + c);
-        } else {
-            for (int c = 0; c < ch; c += 4) *reinterpret_cast<float4 *>(dst + c) = make_float4(0.f, 0.f, 0.f, 0.f);
-        }
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ti >= 0 && ti < T && wi >= 0 && wi < W1) v = *reinterpret_cast<const float4 *>(a0 + (((size_t)b * T + ti) * W1 + wi) * ch + c);
+        *reinterpret_cast<float4 *>(col + pos * Kc + tap * ch + c) = v;
     }
 }
 // da0[b,t,w,ci] = sum over the (<= 4) output positions / taps that read it of dcol
 __global__ void col2im1_kernel(const float *__restrict__ dcol, float *__restrict__ da0, int B, int T, int W1, int W2, int ch) {
-    const int Tp = T / 2, Kc = 9 * ch;
-    const size_t n = (size_t)B * T * W1 * ch;
+    const int Tp = T / 2, Kc = 9 * ch, c4n = ch / 4;
+    const size_t n = (size_t)B * T * W1 * c4n;                      // four channels of an input position per thread (the taps' adds in the same order as before)
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        const int ci = (int)(i % ch);
-        const size_t p = i / ch;
+        const int ci = (int)(i % c4n) * 4;
+        const size_t p = i / c4n;
         const int w = (int)(p % W1), t = (int)((p / W1) % T), b = (int)(p / ((size_t)W1 * T));
-        float acc = 0.f;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int kh = 0; kh < 3; kh++) {
             const int tt = t + 1 - kh;
@@ -158,10 +166,11 @@ __global__ void col2im1_kernel(const float *__restrict__ dcol, float *__restrict
             for (int kw = 0; kw < 3; kw++) {
                 const int ww = w + 1 - kw;
                 if (ww < 0 || (ww & 1) || (ww >> 1) >= W2) continue;
-                acc += dcol[(((size_t)b * Tp + (tt >> 1)) * W2 + (ww >> 1)) * Kc + (kh * 3 + kw) * ch + ci];
+                const float4 v = *reinterpret_cast<const float4 *>(dcol + (((size_t)b * Tp + (tt >> 1)) * W2 + (ww >> 1)) * Kc + (kh * 3 + kw) * ch + ci);
+                acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
             }
         }
-        da0[i] = acc;
+        *reinterpret_cast<float4 *>(da0 + p * ch + ci) = acc;
     }
 }
 // W1 [co][ci][kh][kw] <-> W1r [co][(kh*3+kw)*ch + ci]
@@ -208,12 +217,28 @@ int launch_cnn_seq(float *a1, float *seq, int B, int Tp, int W2, int ch, bool to
 // mode 1: dy = g (plain)             sums of dy and dy * xhat            (BatchNorm backward)
 // mode 2: dy = g * mask * scale * (bn(x) > 0)   the same behind ReLU + dropout (LayerCNN: conv -> BN -> ReLU -> Dropout)
 __device__ __forceinline__ float bn_site_dy(const BnSite &s, float g, float x, float mean, float invstd, float gamma, float beta, size_t row, int f, int F) {
-    // row = (b*T + t)*W + w
-    const int w = (int)(row % s.W), t = (int)((row / s.W) % s.T);
-    const size_t b = row / ((size_t)s.W * s.T);
     const float y = (x - mean) * invstd * gamma + beta;
-    const float m = s.mask ? (float)s.mask[((b * F + f) * s.T + t) * s.W + w] * s.scale : 1.f;
+    const float m = s.mask ? (float)s.mask[row * F + f] * s.scale : 1.f;
     return y > 0.f ? g * m : 0.f;
+}
+// dropout mask of a conv site, [B][F][T*W] (the reference's tensor order) -> [B][T*W][F] (the order of the channels-last rows)
+__global__ __launch_bounds__(256) void mask_rows_kernel(const unsigned char *__restrict__ src, unsigned char *__restrict__ dst, int F, int TW) {
+    __shared__ unsigned char tile[32][33];
+    const size_t base = (size_t)blockIdx.z * F * TW;
+    const int p0 = blockIdx.x * 32, f0 = blockIdx.y * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int j = ty; j < 32; j += 8) {
+        const int f = f0 + j, p_ = p0 + tx;
+        tile[j][tx] = (f < F && p_ < TW) ? src[base + (size_t)f * TW + p_] : 0;
+    }
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8) {
+        const int p_ = p0 + j, f = f0 + tx;
+        if (p_ < TW && f < F) dst[base + (size_t)p_ * F + f] = tile[tx][j];
+    }
+}
+int launch_mask_rows(const unsigned char *src, unsigned char *dst, int B, int F, int TW, hipStream_t st) {
+    hipLaunchKernelGGL(mask_rows_kernel, dim3((TW + 31) / 32, (F + 31) / 32, B), dim3(256), 0, st, src, dst, F, TW);
+    MDD_LAUNCH_CHECK(); return MDD_OK;
 }
 template <int MODE>
 __global__ __launch_bounds__(256) void col_stats_kernel(const float *__restrict__ x, const float *__restrict__ g, size_t R, int F, int rows_per_wg,
@@ -244,6 +269,74 @@ __global__ __launch_bounds__(256) void col_stats_kernel(const float *__restrict_
         atomicAdd(&s2[f], (double)p2[0][tid] + (double)p2[1][tid] + (double)p2[2][tid] + (double)p2[3][tid]);
     }
 }
+// F = 32 (the conv sites: 2e7 elements in 6e5 rows): a lane owns four channels of a row (one 16-byte load), eight lanes a row, a
+// wave eight rows per load instruction (1 KB, contiguous); partial sums per lane in fp32 over <= 32 rows, then fp64.
+template <int MODE>
+__global__ __launch_bounds__(256) void col_stats32_kernel(const float *__restrict__ x, const float *__restrict__ g, size_t R, int rows_per_wg,
+                                                          const float *__restrict__ mean, const float *__restrict__ invstd, const float *__restrict__ gamma,
+                                                          const float *__restrict__ beta, BnSite site, double *__restrict__ s1, double *__restrict__ s2) {
+    constexpr int F = 32;
+    __shared__ float q1[4][F], q2[4][F];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c4 = (lane & 7) * 4, rsub = lane >> 3;
+    const size_t r0 = (size_t)blockIdx.x * rows_per_wg, r1 = min(r0 + (size_t)rows_per_wg, R);
+    float a1[4] = {0.f, 0.f, 0.f, 0.f}, a2[4] = {0.f, 0.f, 0.f, 0.f};
+    float mu[4] = {0.f, 0.f, 0.f, 0.f}, is[4] = {0.f, 0.f, 0.f, 0.f}, ga[4] = {1.f, 1.f, 1.f, 1.f}, be[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        if (MODE != 0) { mu[j] = mean[c4 + j]; is[j] = invstd[c4 + j]; }
+        if (MODE == 2) { ga[j] = gamma[c4 + j]; be[j] = beta[c4 + j]; }
+    }
+    for (size_t r = r0 + wave * 8 + rsub; r < r1; r += 32) {
+        const float4 xq = *reinterpret_cast<const float4 *>(x + r * F + c4);
+        const float xv[4] = {xq.x, xq.y, xq.z, xq.w};
+        if (MODE == 0) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) { a1[j] += xv[j]; a2[j] = fmaf(xv[j], xv[j], a2[j]); }
+        } else {
+            const float4 gq = *reinterpret_cast<const float4 *>(g + r * F + c4);
+            const float gv[4] = {gq.x, gq.y, gq.z, gq.w};
+            uchar4 mq = make_uchar4(1, 1, 1, 1);
+            if (MODE == 2 && site.mask) mq = *reinterpret_cast<const uchar4 *>(site.mask + r * F + c4);
+            const unsigned char mv[4] = {mq.x, mq.y, mq.z, mq.w};
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                float dy = gv[j];
+                if (MODE == 2) {
+                    const float y = (xv[j] - mu[j]) * is[j] * ga[j] + be[j];
+                    const float m = site.mask ? (float)mv[j] * site.scale : 1.f;
+                    dy = y > 0.f ? gv[j] * m : 0.f;
+                }
+                a1[j] += dy; a2[j] = fmaf(dy, (xv[j] - mu[j]) * is[j], a2[j]);
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+#pragma unroll
+        for (int o = 8; o < 64; o <<= 1) { a1[j] += __shfl_xor(a1[j], o); a2[j] += __shfl_xor(a2[j], o); }
+    if (lane < 8) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) { q1[wave][c4 + j] = a1[j]; q2[wave][c4 + j] = a2[j]; }
+    }
+    __syncthreads();
+    if (tid < F) {
+        atomicAdd(&s1[tid], ((double)q1[0][tid] + (double)q1[1][tid]) + ((double)q1[2][tid] + (double)q1[3][tid]));
+        atomicAdd(&s2[tid], ((double)q2[0][tid] + (double)q2[1][tid]) + ((double)q2[2][tid] + (double)q2[3][tid]));
+    }
+}
+template <int MODE>
+static void launch_col_stats(const float *x, const float *g, size_t R, int F, const float *mean, const float *invstd, const float *gamma, const float *beta,
+                             const BnSite &site, double *s1, double *s2, hipStream_t st) {
+    if (F == 32 && (((size_t)x | (size_t)g) & 15) == 0) {
+        const int per = 1024;
+        hipLaunchKernelGGL(col_stats32_kernel<MODE>, dim3((unsigned)((R + per - 1) / per)), dim3(256), 0, st, x, g, R, per, mean, invstd, gamma, beta, site, s1, s2);
+        return;
+    }
+    int per = (int)std::max<size_t>(64, (R + 255) / 256);
+    dim3 grid((F + 63) / 64, (unsigned)((R + per - 1) / per));
+    hipLaunchKernelGGL(col_stats_kernel<MODE>, grid, dim3(256), 0, st, x, g, R, F, per, mean, invstd, gamma, beta, site, s1, s2);
+}
 // mean / biased variance -> invstd; running statistics as nn.BatchNorm does (momentum 0.1, unbiased variance)
 __global__ void bn_finalize_kernel(const double *s1, const double *s2, size_t R, int F, float eps, float momentum, float *mean, float *invstd,
                                    float *running_mean, float *running_var) {
@@ -261,72 +354,119 @@ __global__ void bn_finalize_kernel(const double *s1, const double *s2, size_t R,
     }
 }
 // y = bn(x) [-> relu -> dropout]
-template <int POST>
+// Elementwise BatchNorm kernels: the launch picks a grid whose stride (in elements) is a multiple of F, so a thread meets the same V
+// features in every iteration and keeps their parameters in registers (bn_grid()).
+template <int POST, int V>      // V = 4: F a multiple of 4 and 16-byte aligned buffers: four features of a row per thread
 __global__ void bn_fwd_kernel(const float *__restrict__ x, size_t R, int F, const float *__restrict__ mean, const float *__restrict__ invstd,
                               const float *__restrict__ gamma, const float *__restrict__ beta, BnSite site, float *__restrict__ y) {
-    const size_t n = R * F;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        const int f = (int)(i % F);
-        float v = (x[i] - mean[f]) * invstd[f] * gamma[f] + beta[f];
-        if (POST) {
-            const size_t row = i / F;
-            const int w = (int)(row % site.W), t = (int)((row / site.W) % site.T);
-            const size_t b = row / ((size_t)site.W * site.T);
-            const float m = site.mask ? (float)site.mask[((b * F + f) * site.T + t) * site.W + w] * site.scale : 1.f;
-            v = v > 0.f ? v * m : 0.f;
+    const size_t n = R * F / V, q0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int f = (int)((q0 * V) % F);
+    float mu[V], is[V], ga[V], be[V];
+#pragma unroll
+    for (int j = 0; j < V; j++) { mu[j] = mean[f + j]; is[j] = invstd[f + j]; ga[j] = gamma[f + j]; be[j] = beta[f + j]; }
+    for (size_t q = q0; q < n; q += (size_t)gridDim.x * blockDim.x) {
+        const size_t i = q * V;
+        float xv[V], ov[V];
+        unsigned char mv[V];
+        if (V == 4) {
+            const float4 t = *reinterpret_cast<const float4 *>(x + i); xv[0] = t.x; xv[1 % V] = t.y; xv[2 % V] = t.z; xv[3 % V] = t.w;
+            if (POST && site.mask) { const uchar4 m = *reinterpret_cast<const uchar4 *>(site.mask + i); mv[0] = m.x; mv[1 % V] = m.y; mv[2 % V] = m.z; mv[3 % V] = m.w; }
+        } else {
+            xv[0] = x[i];
+            if (POST && site.mask) mv[0] = site.mask[i];
         }
-        y[i] = v;
+#pragma unroll
+        for (int j = 0; j < V; j++) {
+            float v = (xv[j] - mu[j]) * is[j] * ga[j] + be[j];
+            if (POST) {
+                const float m = site.mask ? (float)mv[j] * site.scale : 1.f;
+                v = v > 0.f ? v * m : 0.f;
+            }
+            ov[j] = v;
+        }
+        if (V == 4) *reinterpret_cast<float4 *>(y + i) = make_float4(ov[0], ov[1 % V], ov[2 % V], ov[3 % V]);
+        else y[i] = ov[0];
     }
 }
 // dx = gamma * invstd * (dy - sum(dy)/R - xhat * sum(dy*xhat)/R);  dgamma = sum(dy*xhat), dbeta = sum(dy)
-template <int MODE>
+template <int MODE, int V>
 __global__ void bn_bwd_kernel(const float *__restrict__ x, const float *__restrict__ g, size_t R, int F, const float *__restrict__ mean,
                               const float *__restrict__ invstd, const float *__restrict__ gamma, const float *__restrict__ beta, BnSite site,
                               const double *__restrict__ s1, const double *__restrict__ s2, float *__restrict__ dx) {
-    const size_t n = R * F;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        const int f = (int)(i % F);
-        const float mu = mean[f], is = invstd[f], ga = gamma[f];
-        const float xv = x[i];
-        const float dy = MODE == 1 ? g[i] : bn_site_dy(site, g[i], xv, mu, is, ga, beta[f], i / F, f, F);
-        const float xh = (xv - mu) * is;
-        dx[i] = ga * is * (dy - (float)(s1[f] / (double)R) - xh * (float)(s2[f] / (double)R));
+    const size_t n = R * F / V, q0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int f = (int)((q0 * V) % F);
+    float mu[V], is[V], ga[V], be[V], m1[V], m2[V];
+#pragma unroll
+    for (int j = 0; j < V; j++) {
+        mu[j] = mean[f + j]; is[j] = invstd[f + j]; ga[j] = gamma[f + j]; be[j] = MODE == 2 ? beta[f + j] : 0.f;
+        m1[j] = (float)(s1[f + j] / (double)R); m2[j] = (float)(s2[f + j] / (double)R);
     }
+    for (size_t q = q0; q < n; q += (size_t)gridDim.x * blockDim.x) {
+        const size_t i = q * V;
+        float xv[V], gv[V], ov[V];
+        unsigned char mv[V];
+        if (V == 4) {
+            const float4 t = *reinterpret_cast<const float4 *>(x + i); xv[0] = t.x; xv[1 % V] = t.y; xv[2 % V] = t.z; xv[3 % V] = t.w;
+            const float4 u = *reinterpret_cast<const float4 *>(g + i); gv[0] = u.x; gv[1 % V] = u.y; gv[2 % V] = u.z; gv[3 % V] = u.w;
+            if (MODE == 2 && site.mask) { const uchar4 m = *reinterpret_cast<const uchar4 *>(site.mask + i); mv[0] = m.x; mv[1 % V] = m.y; mv[2 % V] = m.z; mv[3 % V] = m.w; }
+        } else {
+            xv[0] = x[i]; gv[0] = g[i];
+            if (MODE == 2 && site.mask) mv[0] = site.mask[i];
+        }
+#pragma unroll
+        for (int j = 0; j < V; j++) {
+            float dy = gv[j];
+            if (MODE == 2) {   // behind ReLU + dropout (bn_site_dy's arithmetic)
+                const float yv = (xv[j] - mu[j]) * is[j] * ga[j] + be[j];
+                const float m = site.mask ? (float)mv[j] * site.scale : 1.f;
+                dy = yv > 0.f ? gv[j] * m : 0.f;
+            }
+            const float xh = (xv[j] - mu[j]) * is[j];
+            ov[j] = ga[j] * is[j] * (dy - m1[j] - xh * m2[j]);
+        }
+        if (V == 4) *reinterpret_cast<float4 *>(dx + i) = make_float4(ov[0], ov[1 % V], ov[2 % V], ov[3 % V]);
+        else dx[i] = ov[0];
+    }
+}
+// workgroups of 256 threads such that the grid's stride in elements (grid * 256 * V) is a multiple of F
+static unsigned bn_grid(int F, int V) {
+    int a = F, b = 256 * V;
+    while (b) { const int t_ = a % b; a = b; b = t_; }              // a = gcd(F, 256 * V)
+    const int unit = F / a;                                         // the grid must be a multiple of this
+    return (unsigned)std::max(unit, 4096 / unit * unit);
 }
 __global__ void bn_param_grads_kernel(const double *s1, const double *s2, int F, float *dgamma, float *dbeta) {
     const int f = blockIdx.x * blockDim.x + threadIdx.x;
     if (f < F) { dgamma[f] = (float)s2[f]; dbeta[f] = (float)s1[f]; }
 }
 
-static dim3 stats_grid(size_t R, int F, int *rows_per_wg) {
-    int per = (int)std::max<size_t>(64, (R + 255) / 256);
-    *rows_per_wg = per;
-    return dim3((F + 63) / 64, (unsigned)((R + per - 1) / per));
-}
 int launch_bn_train_fwd(const float *x, size_t R, int F, const float *gamma, const float *beta, float eps, float momentum, float *running_mean,
                         float *running_var, double *s1s2, float *mean, float *invstd, const BnSite *site, float *y, hipStream_t st) {
     MDD_HIP_CHECK(hipMemsetAsync(s1s2, 0, sizeof(double) * 2 * F, st));
-    int per; dim3 grid = stats_grid(R, F, &per);
-    BnSite none{nullptr, 1, 1, 1.f};
-    hipLaunchKernelGGL(col_stats_kernel<0>, grid, dim3(256), 0, st, x, (const float *)nullptr, R, F, per, (const float *)nullptr, (const float *)nullptr,
-                       (const float *)nullptr, (const float *)nullptr, none, s1s2, s1s2 + F);
+    BnSite none{nullptr, 1.f};
+    launch_col_stats<0>(x, nullptr, R, F, nullptr, nullptr, nullptr, nullptr, none, s1s2, s1s2 + F, st);
     hipLaunchKernelGGL(bn_finalize_kernel, dim3((F + 127) / 128), dim3(128), 0, st, s1s2, s1s2 + F, R, F, eps, momentum, mean, invstd, running_mean, running_var);
-    if (site) hipLaunchKernelGGL(bn_fwd_kernel<1>, dim3(4096), dim3(256), 0, st, x, R, F, mean, invstd, gamma, beta, *site, y);
-    else hipLaunchKernelGGL(bn_fwd_kernel<0>, dim3(4096), dim3(256), 0, st, x, R, F, mean, invstd, gamma, beta, none, y);
+    const bool v4 = F % 4 == 0 && (((size_t)x | (size_t)y) & 15) == 0 && (!site || !site->mask || ((size_t)site->mask & 3) == 0);
+    if (site && v4) hipLaunchKernelGGL((bn_fwd_kernel<1, 4>), dim3(bn_grid(F, 4)), dim3(256), 0, st, x, R, F, mean, invstd, gamma, beta, *site, y);
+    else if (site) hipLaunchKernelGGL((bn_fwd_kernel<1, 1>), dim3(bn_grid(F, 1)), dim3(256), 0, st, x, R, F, mean, invstd, gamma, beta, *site, y);
+    else if (v4) hipLaunchKernelGGL((bn_fwd_kernel<0, 4>), dim3(bn_grid(F, 4)), dim3(256), 0, st, x, R, F, mean, invstd, gamma, beta, none, y);
+    else hipLaunchKernelGGL((bn_fwd_kernel<0, 1>), dim3(bn_grid(F, 1)), dim3(256), 0, st, x, R, F, mean, invstd, gamma, beta, none, y);
     MDD_LAUNCH_CHECK();
     return MDD_OK;
 }
 int launch_bn_train_bwd(const float *x, const float *g, size_t R, int F, const float *gamma, const float *beta, const float *mean, const float *invstd,
                         const BnSite *site, double *s1s2, float *dx, float *dgamma, float *dbeta, hipStream_t st) {
     MDD_HIP_CHECK(hipMemsetAsync(s1s2, 0, sizeof(double) * 2 * F, st));
-    int per; dim3 grid = stats_grid(R, F, &per);
-    BnSite none{nullptr, 1, 1, 1.f};
+    BnSite none{nullptr, 1.f};
+    const bool v4 = F % 4 == 0 && (((size_t)x | (size_t)g | (size_t)dx) & 15) == 0 && (!site || !site->mask || ((size_t)site->mask & 3) == 0);
     if (site) {
-        hipLaunchKernelGGL(col_stats_kernel<2>, grid, dim3(256), 0, st, x, g, R, F, per, mean, invstd, gamma, beta, *site, s1s2, s1s2 + F);
-        hipLaunchKernelGGL(bn_bwd_kernel<2>, dim3(4096), dim3(256), 0, st, x, g, R, F, mean, invstd, gamma, beta, *site, s1s2, s1s2 + F, dx);
+        launch_col_stats<2>(x, g, R, F, mean, invstd, gamma, beta, *site, s1s2, s1s2 + F, st);
+        if (v4) hipLaunchKernelGGL((bn_bwd_kernel<2, 4>), dim3(bn_grid(F, 4)), dim3(256), 0, st, x, g, R, F, mean, invstd, gamma, beta, *site, s1s2, s1s2 + F, dx);
+        else hipLaunchKernelGGL((bn_bwd_kernel<2, 1>), dim3(bn_grid(F, 1)), dim3(256), 0, st, x, g, R, F, mean, invstd, gamma, beta, *site, s1s2, s1s2 + F, dx);
     } else {
-        hipLaunchKernelGGL(col_stats_kernel<1>, grid, dim3(256), 0, st, x, g, R, F, per, mean, invstd, gamma, beta, none, s1s2, s1s2 + F);
-        hipLaunchKernelGGL(bn_bwd_kernel<1>, dim3(4096), dim3(256), 0, st, x, g, R, F, mean, invstd, gamma, beta, none, s1s2, s1s2 + F, dx);
+        launch_col_stats<1>(x, g, R, F, mean, invstd, gamma, beta, none, s1s2, s1s2 + F, st);
+        if (v4) hipLaunchKernelGGL((bn_bwd_kernel<1, 4>), dim3(bn_grid(F, 4)), dim3(256), 0, st, x, g, R, F, mean, invstd, gamma, beta, none, s1s2, s1s2 + F, dx);
+        else hipLaunchKernelGGL((bn_bwd_kernel<1, 1>), dim3(bn_grid(F, 1)), dim3(256), 0, st, x, g, R, F, mean, invstd, gamma, beta, none, s1s2, s1s2 + F, dx);
     }
     hipLaunchKernelGGL(bn_param_grads_kernel, dim3((F + 127) / 128), dim3(128), 0, st, s1s2, s1s2 + F, F, dgamma, dbeta);
     MDD_LAUNCH_CHECK();
@@ -339,10 +479,8 @@ __global__ void col_sum_finish_kernel(const double *s1, int F, float *out) {
 // column sums of g [R, F] -> out[F] (bias gradients)
 int launch_col_sum(const float *g, size_t R, int F, double *s1s2, float *out, hipStream_t st) {
     MDD_HIP_CHECK(hipMemsetAsync(s1s2, 0, sizeof(double) * 2 * F, st));
-    int per; dim3 grid = stats_grid(R, F, &per);
-    BnSite none{nullptr, 1, 1, 1.f};
-    hipLaunchKernelGGL(col_stats_kernel<0>, grid, dim3(256), 0, st, g, (const float *)nullptr, R, F, per, (const float *)nullptr, (const float *)nullptr,
-                       (const float *)nullptr, (const float *)nullptr, none, s1s2, s1s2 + F);
+    BnSite none{nullptr, 1.f};
+    launch_col_stats<0>(g, nullptr, R, F, nullptr, nullptr, nullptr, nullptr, none, s1s2, s1s2 + F, st);
     hipLaunchKernelGGL(col_sum_finish_kernel, dim3((F + 127) / 128), dim3(128), 0, st, s1s2, F, out);
     MDD_LAUNCH_CHECK();
     return MDD_OK;
@@ -415,15 +553,20 @@ int launch_softmax_bwd_rows(const float *y, const float *g, size_t R, int n, flo
     MDD_LAUNCH_CHECK(); return MDD_OK;
 }
 // dE[v, :] = sum over positions m = l*B + b with ids[b, l] == v of g[m, :]   (ascending m: deterministic)
-__global__ void embed_bwd_kernel(const float *__restrict__ g, const int64_t *__restrict__ ids, int B, int L, int E, float *__restrict__ dE) {
-    const int v = blockIdx.x, e = blockIdx.y * blockDim.x + threadIdx.x;
-    if (e >= E) return;
+__global__ __launch_bounds__(128) void embed_bwd_kernel(const float *__restrict__ g, const int64_t *__restrict__ ids, int B, int L, int E, float *__restrict__ dE) {
+    __shared__ int sid[1024];                                       // the ids of 1024 positions at a time: only the matching ones touch g
+    const int v = blockIdx.x, e = blockIdx.y * blockDim.x + threadIdx.x, LB = L * B;
     float acc = 0.f;
-    for (int m = 0; m < L * B; m++) {
-        const int l = m / B, b = m - l * B;
-        if (ids[(size_t)b * L + l] == v) acc += g[(size_t)m * E + e];
+    for (int m0 = 0; m0 < LB; m0 += 1024) {
+        const int nm = min(1024, LB - m0);
+        for (int j = threadIdx.x; j < nm; j += blockDim.x) { const int m = m0 + j, l = m / B, b = m - l * B; sid[j] = (int)ids[(size_t)b * L + l]; }
+        __syncthreads();
+        if (e < E)
+            for (int j = 0; j < nm; j++)
+                if (sid[j] == v) acc += g[(size_t)(m0 + j) * E + e];
+        __syncthreads();
     }
-    dE[(size_t)v * E + e] = acc;
+    if (e < E) dE[(size_t)v * E + e] = acc;
 }
 int launch_embed_bwd(const float *g, const int64_t *ids, int B, int L, int E, int rows, float *dE, hipStream_t st) {
     hipLaunchKernelGGL(embed_bwd_kernel, dim3(rows, (E + 127) / 128), dim3(128), 0, st, g, ids, B, L, E, dE);

@@ -22,5 +22,6 @@ python3 $R/tools/pmc_traffic.py $OUT/${TAG}_pmc_fetch $OUT/${TAG}_pmc_write "ben
 stats f32 --precision f32 --steps 16 --warmup 8 $LEAN
 stats ctc --workload ctc256 --steps 50 --warmup 5
 stats train --workload train32 --steps 5 --warmup 2
+stats trainx3 --workload train32 --train-precision bf16x3 --steps 5 --warmup 2
 rm -rf $OUT/${TAG}_*_stats $OUT/${TAG}_pmc_fetch $OUT/${TAG}_pmc_write
 ls $OUT | grep ${TAG}
