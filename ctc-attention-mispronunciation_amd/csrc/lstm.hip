@@ -808,6 +808,226 @@ int launch_lstm_layer_granule(const LstmStepArgs &s, unsigned short *hx, unsigne
     return MDD_ERR_ARG;
 }
 
+
+// ------------------------------------------------------------------------------------------------ persistent BPTT layer kernel
+// The backward recurrence of one bidirectional layer in ONE launch (the split-bf16 training variant; the exact mode keeps one launch
+// per step, train_kernels.hip).  Same grid and teams as the forward layer kernel above (256 workgroups = 2 directions x 16 batch groups
+// x 8 members, one 16-row batch tile per team: B <= 256), the same data-tagged hand-off, the roles transposed:
+//   dh[b, k] = dout[t, b, k] + sum_n DG_prev[b, n] * Whh'[n][k]            (n over the 4H gate rows, k over the H units)
+// A member owns UW = H/8 units k.  Its rows of Whh'^T ([UW][4H], bf16 hi/lo) stay in registers for the whole launch, the
+// contraction's 4H axis split over the four waves (a quarter each, all UT = UW/16 unit tiles), partial tiles summed through LDS.
+// What travels between the members is DG (the gate gradients of the step before): a panel of 4H values per batch row, four times
+// the forward kernel's, as 16-byte chunks {hi x4 | lo x4} of the four gates of ONE unit and row -- exactly what one thread of the
+// cell backward produces, so a chunk goes from the producing thread's registers straight to the exchange buffer (tag bits in the
+// spare last bits of the lo halves, as above).  DG also leaves in fp32 (the weight-gradient and dX products read that).
+struct BwdPersistArgs {
+    const float *dout, *gates, *cst;     // [T][B][2H];  [T][B][2][H][4];  [T][B][2][H]
+    SplitPtr whhT;                       // [2][H][4H] hi/lo: row k of direction d = column k of Whh'_d
+    float *dg;                           // [T][B][2][4H]
+    unsigned short *hx;                  // [2 parity][32 teams][4H/4 chunk columns][16 rows] x 16 B
+    unsigned int *sync;                  // [16] unused, [16] abort flag (zeroed before every launch)
+    int *err_flag;
+    int T, B, BGr;
+};
+
+template <int H>
+__global__ __launch_bounds__(256, 1) void lstm_bwd_granule_kernel(BwdPersistArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int NTH = 256, UW = H / 8, UT = UW / 16, KS = H / 32, G = 4 * H;
+    constexpr int PANB = 16 * G * 4;                                // bytes of a panel
+    constexpr int NLD = PANB / 16 / NTH;                            // 16-byte pieces per thread and sweep
+    constexpr int NE = 16 * UW / NTH;                               // (unit, row) elements per thread in the cell backward
+    static_assert(UW % 16 == 0 && (16 * UW) % NTH == 0 && PANB % (16 * NTH) == 0 && H % 32 == 0, "geometry");
+    unsigned char *Rw = smem;
+    float *red = reinterpret_cast<float *>(smem + PANB);            // [4 waves][UW units][16 rows] partial dh
+    __shared__ int s_fail;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, kq = lane >> 4;
+    const int w = blockIdx.x, xl = w & 7, j = w >> 3;
+    const int team = xl * 4 + (j >> 3), member = j & 7;
+    const int d = team >> 4, g = team & 15;
+    const int B = a.B, T = a.T;
+    if (tid == 0) s_fail = 0;
+
+    bf16x8 ah[UT][KS], al[UT][KS];
+#pragma unroll
+    for (int ut = 0; ut < UT; ut++) {
+        const size_t ro = ((size_t)d * H + member * UW + ut * 16 + li) * G + wave * H + kq * 8;
+#pragma unroll
+        for (int ks = 0; ks < KS; ks++) {
+            ah[ut][ks] = *reinterpret_cast<const bf16x8 *>(a.whhT.hi + ro + ks * 32);
+            al[ut][ks] = *reinterpret_cast<const bf16x8 *>(a.whhT.lo + ro + ks * 32);
+        }
+    }
+    // the cell backward's elements of this thread: e = tid + i * 256 -> (unit e >> 4 of the member's share, tile row e & 15)
+    int unit[NE], brow[NE];
+    bool valid[NE];
+    float dcar[NE];
+#pragma unroll
+    for (int i = 0; i < NE; i++) {
+        const int e = tid + i * NTH, row = e & 15;
+        unit[i] = member * UW + (e >> 4);
+        valid[i] = row < a.BGr && g * a.BGr + row < B;
+        brow[i] = min(g * a.BGr + min(row, a.BGr - 1), B - 1);
+        dcar[i] = 0.f;
+    }
+    constexpr size_t tgran = PANB / 8;                              // 8-byte granules per (parity, team)
+    u64 *hxg = reinterpret_cast<u64 *>(a.hx);
+    unsigned int *abortf = a.sync + 16;
+    const unsigned wave_lds = __builtin_amdgcn_readfirstlane((unsigned)wave * 1024u);
+    const unsigned rw_lds = (unsigned)(unsigned long long)(lds_void_t *)Rw;
+    auto request_sweep = [&](int s) {
+        const unsigned char *srcp = reinterpret_cast<const unsigned char *>(hxg + (size_t)(((s - 1) & 1) * 32 + team) * tgran);
+#pragma unroll
+        for (int i = 0; i < NLD; i++) lds_dma16_s<true>(srcp + (size_t)i * NTH * 16, (unsigned)tid * 16u, rw_lds + (unsigned)(i * NTH * 16) + wave_lds);
+    };
+    // operands of the cell backward at step s: they do not depend on the recurrence and are requested a step ahead
+    float4 pg[NE];
+    float pc[NE], pcp[NE], pdo[NE];
+    auto prefetch = [&](int s) {
+        const int t = d ? s : (T - 1 - s), tp = d ? t + 1 : t - 1;
+#pragma unroll
+        for (int i = 0; i < NE; i++) {
+            const size_t si = (((size_t)t * B + brow[i]) * 2 + d) * H + unit[i];
+            pg[i] = *reinterpret_cast<const float4 *>(a.gates + si * 4);
+            pc[i] = a.cst[si];
+            pcp[i] = (tp >= 0 && tp < T) ? a.cst[(((size_t)tp * B + brow[i]) * 2 + d) * H + unit[i]] : 0.f;
+            pdo[i] = a.dout[((size_t)t * B + brow[i]) * 2 * H + d * H + unit[i]];
+        }
+    };
+    prefetch(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    lds_barrier();
+
+    for (int s = 0; s < T; s++) {
+        const int t = d ? s : (T - 1 - s);
+        if (s > 0) {
+            const unsigned ep = (unsigned)((s - 1) % 3 + 1), etag = (ep & 1u) | ((ep >> 1) << 16);
+            long long t0 = 0;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // own publish acknowledged (a request sent earlier only finds stale tags); prefetch landed
+            request_sweep(s);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            int polls = 0;
+            while (true) {                                          // each wave polls its own pieces (read back through LDS) until all tags match
+                unsigned bad = 0;
+#pragma unroll
+                for (int i = 0; i < NLD; i++) {
+                    const u32x4 v = *reinterpret_cast<const u32x4 *>(Rw + (size_t)(i * NTH + tid) * 16);
+                    bad |= (v[2] ^ etag) | (v[3] ^ etag);
+                }
+                ++polls;
+                if (!__any((bad & 0x00010001u) != 0)) break;
+                if ((polls & 63) == 0) {
+                    int ab = 0;
+                    if (t0 == 0) t0 = wall_clock64();
+                    if (lane == 0) ab = (__hip_atomic_load(abortf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) || (wall_clock64() - t0 > 200000000ll);
+                    if (__any(ab)) {
+                        if (lane == 0) { __hip_atomic_store(abortf, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); atomicExch(a.err_flag, 2); s_fail = 1; }
+                        break;
+                    }
+                }
+                request_sweep(s);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            lds_barrier();                                          // every wave's pieces of the panel are in LDS; s_fail is visible
+            if (s_fail) return;
+            // ---- partial dh of this wave's quarter of the gate axis: operands straight from the travelling chunks
+            f32x4 acc[UT];
+            const unsigned char *fb = Rw + (size_t)((wave * (H / 4) + kq * 2) * 16 + li) * 16;
+            constexpr int PD = 3;
+            u32x4 ra[PD], rb[PD];
+#pragma unroll
+            for (int p = 0; p < PD; p++) {
+                ra[p] = *reinterpret_cast<const u32x4 *>(fb + p * 2048);
+                rb[p] = *reinterpret_cast<const u32x4 *>(fb + p * 2048 + 256);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int ks = 0; ks < KS; ks++) {
+                const u32x4 xa = ra[ks % PD], xb = rb[ks % PD];
+                if (ks + PD < KS) {
+                    ra[ks % PD] = *reinterpret_cast<const u32x4 *>(fb + (ks + PD) * 2048);
+                    rb[ks % PD] = *reinterpret_cast<const u32x4 *>(fb + (ks + PD) * 2048 + 256);
+                }
+                u32x4 hq, lq;
+                hq[0] = xa[0]; hq[1] = xa[1]; hq[2] = xb[0]; hq[3] = xb[1];
+                lq[0] = xa[2] & 0xfffefffeu; lq[1] = xa[3] & 0xfffefffeu; lq[2] = xb[2] & 0xfffefffeu; lq[3] = xb[3] & 0xfffefffeu;
+                const bf16x8 bh = __builtin_bit_cast(bf16x8, hq), bl = __builtin_bit_cast(bf16x8, lq);
+#pragma unroll
+                for (int ut = 0; ut < UT; ut++)
+                    acc[ut] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[ut][ks], bl, ks == 0 ? (f32x4){0.f, 0.f, 0.f, 0.f} : acc[ut], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int ut = 0; ut < UT; ut++) mfma_a(acc[ut], al[ut][ks], bh);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int ut = 0; ut < UT; ut++) acc[ut] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[ut][ks], bh, acc[ut], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // D layout: row (unit of the tile) = 4 * kq + r, column (batch row) = li
+#pragma unroll
+            for (int ut = 0; ut < UT; ut++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) red[((wave * UW) + ut * 16 + 4 * kq + r) * 16 + li] = acc[ut][r];
+            lds_barrier();
+        }
+        // ---- cell backward of this thread's elements; DG_t to the team (tagged chunks) and to memory (fp32)
+        const unsigned tg = (unsigned)(s % 3 + 1);
+        const bool pub = s + 1 < T;
+        const __amdgpu_buffer_rsrc_t drs = __builtin_amdgcn_make_buffer_rsrc(hxg + (size_t)((s & 1) * 32 + team) * tgran, 0, PANB, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < NE; i++) {
+            const int e = tid + i * NTH;
+            float dh = pdo[i];
+            if (s > 0) dh += (red[e] + red[UW * 16 + e]) + (red[2 * UW * 16 + e] + red[3 * UW * 16 + e]);
+            const float gi = pg[i].x, gf = pg[i].y, gg = pg[i].z, go = pg[i].w;
+            const float th = tanhf(pc[i]);
+            const float dcell = dh * go * (1.f - th * th) + dcar[i];
+            float d_o = dh * th * go * (1.f - go);
+            float d_i = dcell * gg * gi * (1.f - gi);
+            float d_f = dcell * pcp[i] * gf * (1.f - gf);
+            float d_g = dcell * gi * (1.f - gg * gg);
+            dcar[i] = dcell * gf;
+            if (!valid[i]) { d_i = d_f = d_g = d_o = 0.f; dcar[i] = 0.f; }
+            if (valid[i])
+                *reinterpret_cast<float4 *>(a.dg + (((size_t)t * B + brow[i]) * 2 + d) * G + unit[i] * 4) = make_float4(d_i, d_f, d_g, d_o);
+            if (pub) {   // chunk = {hi_i hi_f | hi_g hi_o | lo_i' lo_f' | lo_g' lo_o'}: tag bit 0 rides in the even values' lo, bit 1 in the odd ones'
+                const unsigned wi = split_h(d_i), wf = split_h(d_f), wg = split_h(d_g), wo = split_h(d_o);
+                u32x4 pv;
+                pv[0] = (wi & 0xffffu) | (wf << 16);
+                pv[1] = (wg & 0xffffu) | (wo << 16);
+                pv[2] = ((wi >> 16) | (tg & 1u)) | (((wf >> 16) | (tg >> 1)) << 16);
+                pv[3] = ((wg >> 16) | (tg & 1u)) | (((wo >> 16) | (tg >> 1)) << 16);
+                __builtin_amdgcn_raw_buffer_store_b128(pv, drs, (unsigned)((member * UW * 16 + e) * 16), 0, 16 /* sc1 */);
+            }
+        }
+        if (s + 1 < T) prefetch(s + 1);
+    }
+}
+
+template <int H>
+static int launch_bwd_granule_t(const BwdPersistArgs &a, hipStream_t st) {
+    constexpr size_t panb = (size_t)16 * 4 * H * 4;
+    const size_t smem = panb + (size_t)4 * (H / 8) * 16 * 4;
+    MDD_HIP_CHECK(hipMemsetAsync(a.sync, 0, 32 * sizeof(unsigned int), st));
+    MDD_HIP_CHECK(hipMemsetAsync(a.hx, 0, (size_t)2 * 32 * panb, st));   // tags must start at 0 on every launch
+    hipLaunchKernelGGL((lstm_bwd_granule_kernel<H>), dim3(256), dim3(256), smem, st, a);
+    MDD_LAUNCH_CHECK();
+    return MDD_OK;
+}
+size_t lstm_bwd_granule_hx_bytes(int H) { return (size_t)2 * 32 * 16 * 4 * H * 4; }
+int launch_lstm_bwd_granule(const float *dout, const float *gates, const float *cst, SplitPtr whhT, float *dg, int T, int B, int H, unsigned short *hx,
+                            unsigned int *sync, int *err_flag, hipStream_t st) {
+    BwdPersistArgs a;
+    a.dout = dout; a.gates = gates; a.cst = cst; a.whhT = whhT; a.dg = dg; a.hx = hx; a.sync = sync; a.err_flag = err_flag;
+    a.T = T; a.B = B; a.BGr = (B + 15) / 16;
+    if (T <= 0 || B <= 0 || a.BGr > 16) { set_error("persistent lstm backward: B=%d needs more than one tile per team (max 256)", B); return MDD_ERR_ARG; }
+    if (H == 384) return launch_bwd_granule_t<384>(a, st);
+    if (H == 256) return launch_bwd_granule_t<256>(a, st);
+    set_error("persistent lstm backward: unsupported H=%d", H);
+    return MDD_ERR_ARG;
+}
+
 int init_granule_attributes() {
 #define GATTR(H, N, R) MDD_HIP_CHECK(hipFuncSetAttribute((const void *)lstm_layer_granule_kernel<H, N, R>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024))
     GATTR(384, 1, 3); GATTR(384, 2, 3); GATTR(384, 3, 3); GATTR(384, 4, 3); GATTR(256, 1, 2); GATTR(256, 2, 2); GATTR(256, 3, 2); GATTR(256, 4, 2);
@@ -815,6 +1035,8 @@ int init_granule_attributes() {
 #define GATTR(H, N, R) MDD_HIP_CHECK(hipFuncSetAttribute((const void *)lstm_layer_granule_kernel<H, N, R, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024))
     GATTR(384, 1, 3); GATTR(384, 2, 3); GATTR(256, 1, 2); GATTR(256, 2, 2);
 #undef GATTR
+    MDD_HIP_CHECK(hipFuncSetAttribute((const void *)lstm_bwd_granule_kernel<384>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
+    MDD_HIP_CHECK(hipFuncSetAttribute((const void *)lstm_bwd_granule_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
     return MDD_OK;
 }
 

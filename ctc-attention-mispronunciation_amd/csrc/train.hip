@@ -366,7 +366,16 @@ static int lstm_backward(mdd_train_ws *w, int n, int Tn, int B, int K, const flo
     TRY(launch_transpose_whh(w->whhp[n].p, w->whht[n].p, H, st));
     LstmBwdArgs a;
     a.dout = dout; a.gates = w->gates[n].p; a.cst = w->cst[n].p; a.whhT = w->whht[n].p; a.dg = w->dgx.p; a.dc = w->cb.p; a.T = Tn; a.B = B; a.H = H;
-    TRY(launch_lstm_bwd(a, st));
+    if (w->precision == 1 && w->persist_ok && (H == 384 || H == 256) && B <= 256) {   // flagged variant: the whole recurrence in one persistent launch
+        const size_t nW = (size_t)8 * H * H;
+        TRY(w->whhs.need(nW));
+        unsigned short *hi = reinterpret_cast<unsigned short *>(w->whhs.p), *lo = hi + nW;
+        TRY(launch_split_rows(w->whht[n].p, G, (size_t)2 * H, G, G, hi, lo, st));
+        TRY(w->hx.need(lstm_bwd_granule_hx_bytes(H) / 4));
+        TRY(launch_lstm_bwd_granule(dout, a.gates, a.cst, SplitPtr{hi, lo}, a.dg, Tn, B, H, reinterpret_cast<unsigned short *>(w->hx.p), w->sync_words, w->err_flag + 1, st));
+    } else {
+        TRY(launch_lstm_bwd(a, st));
+    }
     // dWih' [2*4H, K] = DG^T . xin ;  dWhh'[d] [4H, H] = DG_d^T . h_prev_d  (h_prev = the layer's raw output one step earlier in that direction)
     TRY(w->d_b.need((size_t)G2 * std::max(K, H)));
     TRY(gemm_big(w, true, true, w->dgx.p, G2, xin, K, nullptr, w->d_b.p, K, G2, K, (int)rows, st));
@@ -385,7 +394,16 @@ static int lstm_backward(mdd_train_ws *w, int n, int Tn, int B, int K, const flo
 
 #define GR(key) (grads[idx(w, key)])
 
+static int train_backward_enqueue(mdd_train_ws *w, float *const *tensors, const float *dlogp_dev, float *const *grads, void *stream);
 extern "C" int mdd_train_backward(mdd_train_ws *w, float *const *tensors, const float *dlogp_dev, float *const *grads, void *stream) {
+    if (!w) { set_error("mdd_train_backward: null handle"); return MDD_ERR_ARG; }
+    const bool gated = w->precision == 1 && w->persist_ok;      // persistent launches inside: one at a time per device
+    bool held = false;
+    if (gated) { MDD_HIP_CHECK(hipSetDevice(w->device)); if (int rc = device_gate_enter(w->device, (hipStream_t)stream, &held)) return rc; }
+    const int rc = train_backward_enqueue(w, tensors, dlogp_dev, grads, stream);
+    return gated ? device_gate_leave(w->device, (hipStream_t)stream, held, rc) : rc;
+}
+static int train_backward_enqueue(mdd_train_ws *w, float *const *tensors, const float *dlogp_dev, float *const *grads, void *stream) {
     if (!w || !tensors || !dlogp_dev || !grads || w->B <= 0) { set_error("mdd_train_backward: bad argument (forward first)"); return MDD_ERR_ARG; }
     MDD_HIP_CHECK(hipSetDevice(w->device));
     hipStream_t st = (hipStream_t)stream;

@@ -726,12 +726,13 @@ def test_train_step_against_torch_restatement(H, B, T, L):
             np.testing.assert_allclose(b_.cpu().numpy(), run[k], rtol=0, atol=1e-5, err_msg=k)
 
 
-@pytest.mark.parametrize("H,B,T,L", [(384, 32, 160, 12), (256, 272, 16, 5)])
+@pytest.mark.parametrize("H,B,T,L", [(384, 32, 160, 12), (256, 272, 16, 5), (256, 100, 24, 5), (384, 7, 40, 6)])
 def test_train_step_split_bf16_variant(H, B, T, L):
     """The flagged variant of the training step (model.train_precision = "bf16x3": input projections, dX and dW_ih through the
     split-bf16 x3 matrix-core GEMM, the weight gradients with the row axis cut into partial products, the forward recurrences in the
-    persistent layer kernel with h carried as bf16 hi/lo) at sizes where every one of those paths is taken (B=32, T=160: 2560 rows,
-    one batch tile per team; B=272, H=256: two tiles per team), beside the exact mode, both against the restatement run in DOUBLE (at this size
+    persistent layer kernel with h carried as bf16 hi/lo, the backward recurrences in the persistent BPTT kernel with the gate gradients
+    travelling as bf16 hi/lo) at sizes where every one of those paths is taken (B=32, T=160: 2560 rows, one batch tile per team;
+    B=272, H=256: two tiles per team forward, per-step backward; B=100 and B=7: ragged team rows), beside the exact mode, both against the restatement run in DOUBLE (at this size
     torch's own fp32 evaluation is 5e-5..9e-5 of scale away from double, so it is no yardstick).
     Exact mode: log-probs 1e-4, every gradient outside the CNN within 2e-5 of its scale (measured 7e-6).
     Variant (operands carry 16 mantissa bits): log-probs 5e-4 (logits of magnitude ~16 after four layers), gradients 2e-4 of scale.
