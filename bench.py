@@ -14,8 +14,9 @@ reference masks nothing, so an utterance's result depends on its batch's padded 
 DIFFERENT padded lengths in one launch sequence with per-row (T_g, L_g), bit-identical to running each batch alone.  What real
 (ragged) data gets is reported in the same JSON line under `variants` (same run, rank 0, N=1): `ragged` (len ~ U[0.5,1] x 10 s,
 every batch padded to its own maximum, 8 such batches per fused pass, frames counted UNPADDED), `ragged_fuse1` / `fuse1` (a lone
-B=64 batch per pass: the latency-bound case), `f32_mode` (exact-fp32 MFMA arithmetic, MDD_PRECISION=f32) and `greedy32_h256`
-(configs[1]).
+B=64 batch per pass: the latency-bound case), `f32_mode` (exact-fp32 MFMA arithmetic, MDD_PRECISION=f32), `greedy32_h256`
+(configs[1]) and `train32_f32` / `train32_bf16x3` (configs[4]'s per-GPU shard: a full training step in exact fp32 and in the flagged
+split-bf16 variant; `--workload train32 [--train-precision bf16x3]` prints that line on its own, with the stage split).
 
 N>1 (launched by torch.distributed.run, one rank per GPU): utterance batches shard across ranks (weak
 scaling: every rank decodes its own 64-utterance batch) and the posteriors of all shards are all-gathered
@@ -533,8 +534,9 @@ def main():
                               "unit": "phoneme-frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                               "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                               "dtype": ("f32 (exact fp32 MFMA; the reference trains in fp32)" if args.train_precision == "f32" else
-                                        "f32 with the projection GEMMs (forward, dX, dW_ih) as split-bf16 x3 on the bf16 matrix cores; recurrences, "
-                                        "BatchNorm, attention, CTC in fp32/fp64"), "data": "synthetic",
+                                        "f32 with the projections (forward, dX, dW_ih) and both recurrences (W_hh.h forward, DG.W_hh backward, in the persistent "
+                                        "layer kernels, h and the gate gradients carried as bf16 hi/lo) as split-bf16 x3 on the bf16 matrix cores; "
+                                        "conv, BatchNorm, attention, cell math, weight gradients of W_hh, CTC in fp32/fp64"), "data": "synthetic",
                               "config": {"workload": "training step, B=32 per GPU x 10 s (global batch 32 x n_gpus; BASELINE configs[4] = 8 x 32), H=%d, L=40, dropout 0.2, "
                                                      "Adam lr 1e-3 wd 5e-4" % args.hidden, **info},
                               "roofline": {"kernel": "training step (all kernels)", "bound": "mfma", "achieved": round(flop / (dt / args.steps) / 1e12, 2),
@@ -602,6 +604,13 @@ def main():
             "greedy32_h256_fuse1": variant(ctx, args, "greedy32_h256_fuse1", hidden=256, joint=False, fuse=1, ragged=False, precision=args.precision,
                                            steps=32, warmup=8),
         }
+        for mode in ("f32", "bf16x3"):          # BASELINE configs[4]'s per-GPU shard: one full training step (--workload train32 has the stage split)
+            targs = argparse.Namespace(**dict(vars(args), steps=10, warmup=3, train_precision=mode))
+            tdt, tframes, tinfo = train_workload(ctx, targs)
+            variants["train32_" + mode] = {"value": round(tframes / tdt, 1), "unit": "phoneme-frames/s", "ms_per_step": round(tdt / targs.steps * 1e3, 3),
+                                           "steps": targs.steps, "batch": 32, "precision": mode, "forward_ms": tinfo["forward_ms"],
+                                           "loss_backward_ms": tinfo["loss_backward_ms"], "adam_ms": tinfo["adam_ms"]}
+            torch.cuda.empty_cache()
 
     if rank == 0:
         B0 = 64 if joint else 32
@@ -628,7 +637,7 @@ def main():
         if gather_ok is not None:
             line["gather_verified"] = gather_ok
         if variants:
-            for k in ("fuse1", "ragged", "f32_mode", "greedy32_h256"):
+            for k in ("fuse1", "ragged", "f32_mode", "greedy32_h256", "train32_f32", "train32_bf16x3"):
                 line[k] = variants[k]["value"]
         print(json.dumps(line))
     if ctx.dist is not None:

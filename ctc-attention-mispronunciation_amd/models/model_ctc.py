@@ -110,6 +110,7 @@ class CTC_Model(nn.Module):
         self._dirty = True
         self.strict_errors = True   # raise IndexError for bad canonical ids synchronously, like nn.Embedding
         self._dropout_masks = None  # tests: the reference's own dropout masks (one uint8 tensor per site, mdd_hip.h); None = drawn
+        self.train_precision = None  # train mode: None = library default (exact fp32, or MDD_TRAIN_PRECISION), "f32", or "bf16x3" (flagged variant)
 
     # ------------------------------------------------------------------ library plumbing
     def _check_supported(self):

@@ -1,6 +1,10 @@
 set -e
 mkdir -p gpurun_out
-timeout -k 10 300 python -m pytest tests/test_gpu_parity.py -q -x -s -k "split_bf16_variant" > gpurun_out/t_train.log 2>&1 || { tail -40 gpurun_out/t_train.log; exit 1; }
-tail -3 gpurun_out/t_train.log
-timeout -k 10 200 python bench.py --workload train32 --steps 20 --warmup 3 --train-precision bf16x3 > gpurun_out/train_x3.json 2> gpurun_out/train_x3.err
-cat gpurun_out/train_x3.json | cut -c1-900
+( time timeout -k 10 600 python bench.py --steps 20 --warmup 5 > gpurun_out/bench_driver_style.json 2> gpurun_out/bench_driver_style.err ) 2> gpurun_out/bench_time.txt
+cat gpurun_out/bench_time.txt | tail -4
+python - <<'PY'
+import json
+d=json.load(open('gpurun_out/bench_driver_style.json'))
+print({k:d[k] for k in ("value","fuse1","ragged","f32_mode","greedy32_h256","train32_f32","train32_bf16x3")})
+print(d["variants"]["train32_bf16x3"])
+PY
