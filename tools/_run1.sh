@@ -1,10 +1,10 @@
 set -e
 mkdir -p gpurun_out
-( time timeout -k 10 600 python bench.py --steps 20 --warmup 5 > gpurun_out/bench_driver_style.json 2> gpurun_out/bench_driver_style.err ) 2> gpurun_out/bench_time.txt
-cat gpurun_out/bench_time.txt | tail -4
+timeout -k 10 300 python bench.py --hidden 256 --steps 64 --warmup 16 --no-variants --no-cpu-baseline > gpurun_out/bench_kh2.json 2> gpurun_out/bench_kh2.err
+MDD_LSTM_WAVES=4 timeout -k 10 300 python bench.py --hidden 256 --steps 64 --warmup 16 --no-variants --no-cpu-baseline > gpurun_out/bench_kh1.json 2> gpurun_out/bench_kh1.err
 python - <<'PY'
 import json
-d=json.load(open('gpurun_out/bench_driver_style.json'))
-print({k:d[k] for k in ("value","fuse1","ragged","f32_mode","greedy32_h256","train32_f32","train32_bf16x3")})
-print(d["variants"]["train32_bf16x3"])
+for n in ("kh2","kh1"):
+    d=json.load(open('gpurun_out/bench_%s.json'%n))
+    print(n, d["value"], d["ms_per_step"], d["roofline"].get("kernel_classes_ms"))
 PY
