@@ -22,8 +22,9 @@ def allreduce_gradients(model, bucket_bytes=64 << 20):
     """Average the gradients over the ranks (RCCL all-reduce over xGMI on ROCm; no-op without an initialised process group).
     Gradients are packed into buckets of ~64 MB so the ring moves few large messages (21 M parameters = 85 MB: two buckets)."""
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
-        return
+    import os
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size() == 1 and not os.environ.get("MDD_FORCE_DIST")):
+        return                                       # (MDD_FORCE_DIST: rehearse the collective path on a one-rank group)
     world = dist.get_world_size()
     grads = [p.grad for p in model.parameters() if p.grad is not None]
     bucket, size = [], 0
