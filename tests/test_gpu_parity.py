@@ -851,6 +851,35 @@ def test_train_mode_generated_masks_and_full_loop():
     assert torch.isfinite(ev).all() and float(torch.exp(ev.double()).sum(-1).sub(1).abs().max()) < 1e-5
 
 
+def test_train_variant_soak_and_eval_consistency():
+    """60 optimizer steps in the flagged split-bf16 variant (both persistent recurrences, 2 x 5 launches per step, device gate taken and
+    released each time): no hand-off time-out (mdd_train_sync raises on one), the loss falls, and the eval path afterwards (which
+    re-packs the trained weights) gives normalised posteriors."""
+    from ctc_attention_mispronunciation_amd.train import CTCLoss, Adam
+    geom = synth.Geometry(**synth.REFERENCE)
+    B, T, L = 24, 64, 8
+    sd, x, x1, _, tg, il, tl = synth.train_case(geom, 11, B, T, L, 5)
+    model = _train_model(geom, sd)
+    model.train_precision = "bf16x3"
+    xd, x1d = _cuda(x), _cuda(x1)
+    opt = Adam(model.parameters(), lr=1e-3, weight_decay=5e-4)
+    crit = CTCLoss(reduction="sum")
+    tgd, ild, tld = torch.from_numpy(tg), torch.from_numpy(il), torch.from_numpy(tl)
+    losses = []
+    for _ in range(60):
+        out = model(xd, x1d)
+        loss = crit(out, tgd, ild, tld) / B
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        losses.append(float(loss.detach()))
+    assert all(np.isfinite(losses)) and losses[-1] < 0.7 * losses[0], (losses[0], losses[-1])
+    model.eval()
+    with torch.no_grad():
+        ev = model(xd, x1d)
+    assert torch.isfinite(ev).all() and float(torch.exp(ev.double()).sum(-1).sub(1).abs().max()) < 1e-5
+
+
 def test_run_epoch_mirror_trains_and_validates():
     """steps/train_ctc.run_epoch (the reference's loop, train_ctc.py:28-105) over an in-memory loader of create_input batches:
     a training epoch then a validation epoch; returns (accuracy, mean loss), parameters move only in training."""
