@@ -235,6 +235,12 @@ class CTC_Model(nn.Module):
             toks += len(label)
         return errs, toks
 
+    def add_weights_noise(self):
+        """model_ctc.py:246-249: draws N(0, 0.075) noise per parameter and binds the sum to a LOCAL name -- the parameters are left
+        as they are; what the call does observably is advance the generator, which is kept."""
+        for param in self.parameters():
+            param.data.new(param.size()).normal_(0, 0.075)
+
     @staticmethod
     def save_package(model, optimizer=None, decoder=None, epoch=None, loss_results=None, dev_loss_results=None,
                      dev_cer_results=None):
