@@ -834,10 +834,14 @@ template <int H>
 __global__ __launch_bounds__(256, 1) void lstm_bwd_granule_kernel(BwdPersistArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int NTH = 256, UW = H / 8, UT = UW / 16, KS = H / 32, G = 4 * H;
-    constexpr int PANB = 16 * G * 4;                                // bytes of a panel
-    constexpr int NLD = PANB / 16 / NTH;                            // 16-byte pieces per thread and sweep
-    constexpr int NE = 16 * UW / NTH;                               // (unit, row) elements per thread in the cell backward
+    constexpr int ROWB = G * 4;                                     // bytes of one batch row of a panel: G/4 chunks of 16 B
+    constexpr int PANB = 16 * ROWB;                                 // bytes of a panel
+    constexpr int NLD = PANB / 16 / NTH;                            // 16-byte pieces per thread for a full panel
+    constexpr int NE = 16 * UW / NTH;                               // (row, unit) elements per thread in the cell backward
     static_assert(UW % 16 == 0 && (16 * UW) % NTH == 0 && PANB % (16 * NTH) == 0 && H % 32 == 0, "geometry");
+    // Panel layout, in the exchange buffer and in LDS alike (the sweep is a linear copy): ROW-major, so that only the team's real rows
+    // travel (2 of 16 at B = 32); inside a row the chunk of unit u sits at position u ^ row: the 16 lanes of an MFMA operand read
+    // (same chunk column, rows 0..15) then hit 16 different 16-byte bank groups instead of one.
     unsigned char *Rw = smem;
     float *red = reinterpret_cast<float *>(smem + PANB);            // [4 waves][UW units][16 rows] partial dh
     __shared__ int s_fail;
@@ -847,6 +851,7 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_granule_kernel(BwdPersistArgs
     const int team = xl * 4 + (j >> 3), member = j & 7;
     const int d = team >> 4, g = team & 15;
     const int B = a.B, T = a.T;
+    const int nrows = max(0, min(a.BGr, B - g * a.BGr));            // real rows of this team's tile (workgroup-uniform)
     if (tid == 0) s_fail = 0;
 
     bf16x8 ah[UT][KS], al[UT][KS];
@@ -859,16 +864,17 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_granule_kernel(BwdPersistArgs
             al[ut][ks] = *reinterpret_cast<const bf16x8 *>(a.whhT.lo + ro + ks * 32);
         }
     }
-    // the cell backward's elements of this thread: e = tid + i * 256 -> (unit e >> 4 of the member's share, tile row e & 15)
-    int unit[NE], brow[NE];
+    // the cell backward's elements of this thread: e = tid + i * 256 -> (tile row e / UW, unit e % UW of the member's share): the real
+    // rows come first, so with few rows most threads have nothing to do after the first element
+    int ul[NE], row[NE], brow[NE];
     bool valid[NE];
     float dcar[NE];
 #pragma unroll
     for (int i = 0; i < NE; i++) {
-        const int e = tid + i * NTH, row = e & 15;
-        unit[i] = member * UW + (e >> 4);
-        valid[i] = row < a.BGr && g * a.BGr + row < B;
-        brow[i] = min(g * a.BGr + min(row, a.BGr - 1), B - 1);
+        const int e = tid + i * NTH;
+        row[i] = e / UW; ul[i] = e - row[i] * UW;
+        valid[i] = row[i] < nrows;
+        brow[i] = min(g * a.BGr + min(row[i], max(nrows, 1) - 1), B - 1);
         dcar[i] = 0.f;
     }
     constexpr size_t tgran = PANB / 8;                              // 8-byte granules per (parity, team)
@@ -876,10 +882,10 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_granule_kernel(BwdPersistArgs
     unsigned int *abortf = a.sync + 16;
     const unsigned wave_lds = __builtin_amdgcn_readfirstlane((unsigned)wave * 1024u);
     const unsigned rw_lds = (unsigned)(unsigned long long)(lds_void_t *)Rw;
+    const int npc = (nrows * ROWB + NTH * 16 - 1) / (NTH * 16);     // 4 KB passes that cover the real rows (workgroup-uniform)
     auto request_sweep = [&](int s) {
         const unsigned char *srcp = reinterpret_cast<const unsigned char *>(hxg + (size_t)(((s - 1) & 1) * 32 + team) * tgran);
-#pragma unroll
-        for (int i = 0; i < NLD; i++) lds_dma16_s<true>(srcp + (size_t)i * NTH * 16, (unsigned)tid * 16u, rw_lds + (unsigned)(i * NTH * 16) + wave_lds);
+        for (int i = 0; i < npc; i++) lds_dma16_s<true>(srcp + (size_t)i * NTH * 16, (unsigned)tid * 16u, rw_lds + (unsigned)(i * NTH * 16) + wave_lds);
     };
     // operands of the cell backward at step s: they do not depend on the recurrence and are requested a step ahead
     float4 pg[NE];
@@ -888,20 +894,24 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_granule_kernel(BwdPersistArgs
         const int t = d ? s : (T - 1 - s), tp = d ? t + 1 : t - 1;
 #pragma unroll
         for (int i = 0; i < NE; i++) {
-            const size_t si = (((size_t)t * B + brow[i]) * 2 + d) * H + unit[i];
+            if (!valid[i]) continue;
+            const int unit = member * UW + ul[i];
+            const size_t si = (((size_t)t * B + brow[i]) * 2 + d) * H + unit;
             pg[i] = *reinterpret_cast<const float4 *>(a.gates + si * 4);
             pc[i] = a.cst[si];
-            pcp[i] = (tp >= 0 && tp < T) ? a.cst[(((size_t)tp * B + brow[i]) * 2 + d) * H + unit[i]] : 0.f;
-            pdo[i] = a.dout[((size_t)t * B + brow[i]) * 2 * H + d * H + unit[i]];
+            pcp[i] = (tp >= 0 && tp < T) ? a.cst[(((size_t)tp * B + brow[i]) * 2 + d) * H + unit] : 0.f;
+            pdo[i] = a.dout[((size_t)t * B + brow[i]) * 2 * H + d * H + unit];
         }
     };
+#pragma unroll
+    for (int i = 0; i < NE; i++) { pg[i] = make_float4(0.f, 0.f, 0.f, 0.f); pc[i] = pcp[i] = pdo[i] = 0.f; }
     prefetch(0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     lds_barrier();
 
     for (int s = 0; s < T; s++) {
         const int t = d ? s : (T - 1 - s);
-        if (s > 0) {
+        if (s > 0 && nrows > 0) {
             const unsigned ep = (unsigned)((s - 1) % 3 + 1), etag = (ep & 1u) | ((ep >> 1) << 16);
             long long t0 = 0;
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // own publish acknowledged (a request sent earlier only finds stale tags); prefetch landed
@@ -910,10 +920,12 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_granule_kernel(BwdPersistArgs
             int polls = 0;
             while (true) {                                          // each wave polls its own pieces (read back through LDS) until all tags match
                 unsigned bad = 0;
-#pragma unroll
-                for (int i = 0; i < NLD; i++) {
-                    const u32x4 v = *reinterpret_cast<const u32x4 *>(Rw + (size_t)(i * NTH + tid) * 16);
-                    bad |= (v[2] ^ etag) | (v[3] ^ etag);
+                for (int i = 0; i < npc; i++) {
+                    const int off = (i * NTH + tid) * 16;
+                    if (off < nrows * ROWB) {                       // (the last pass may run past the real rows)
+                        const u32x4 v = *reinterpret_cast<const u32x4 *>(Rw + off);
+                        bad |= (v[2] ^ etag) | (v[3] ^ etag);
+                    }
                 }
                 ++polls;
                 if (!__any((bad & 0x00010001u) != 0)) break;
@@ -931,23 +943,29 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_granule_kernel(BwdPersistArgs
             }
             lds_barrier();                                          // every wave's pieces of the panel are in LDS; s_fail is visible
             if (s_fail) return;
-            // ---- partial dh of this wave's quarter of the gate axis: operands straight from the travelling chunks
+            // ---- partial dh of this wave's quarter of the gate axis: operands straight from the travelling chunks.  Lane (row li,
+            // k-quarter kq) at k-step ks needs chunk columns c, c + 1 (c = wave * H/4 + ks * 8 + kq * 2, even) of row li: positions
+            // c ^ li and (c ^ li) ^ 1.  Rows past the team's real ones were never fetched: whatever LDS holds there only reaches
+            // the output columns of those rows, which nobody reads.
             f32x4 acc[UT];
-            const unsigned char *fb = Rw + (size_t)((wave * (H / 4) + kq * 2) * 16 + li) * 16;
+            const unsigned char *rb_ = Rw + (size_t)li * ROWB;
+            const int c0 = wave * (H / 4) + kq * 2;
             constexpr int PD = 3;
             u32x4 ra[PD], rb[PD];
 #pragma unroll
             for (int p = 0; p < PD; p++) {
-                ra[p] = *reinterpret_cast<const u32x4 *>(fb + p * 2048);
-                rb[p] = *reinterpret_cast<const u32x4 *>(fb + p * 2048 + 256);
+                const int c = (c0 + p * 8) ^ li;
+                ra[p] = *reinterpret_cast<const u32x4 *>(rb_ + c * 16);
+                rb[p] = *reinterpret_cast<const u32x4 *>(rb_ + (c ^ 1) * 16);
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int ks = 0; ks < KS; ks++) {
                 const u32x4 xa = ra[ks % PD], xb = rb[ks % PD];
                 if (ks + PD < KS) {
-                    ra[ks % PD] = *reinterpret_cast<const u32x4 *>(fb + (ks + PD) * 2048);
-                    rb[ks % PD] = *reinterpret_cast<const u32x4 *>(fb + (ks + PD) * 2048 + 256);
+                    const int c = (c0 + (ks + PD) * 8) ^ li;
+                    ra[ks % PD] = *reinterpret_cast<const u32x4 *>(rb_ + c * 16);
+                    rb[ks % PD] = *reinterpret_cast<const u32x4 *>(rb_ + (c ^ 1) * 16);
                 }
                 u32x4 hq, lq;
                 hq[0] = xa[0]; hq[1] = xa[1]; hq[2] = xb[0]; hq[3] = xb[1];
@@ -977,20 +995,19 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_granule_kernel(BwdPersistArgs
         const __amdgpu_buffer_rsrc_t drs = __builtin_amdgcn_make_buffer_rsrc(hxg + (size_t)((s & 1) * 32 + team) * tgran, 0, PANB, 0x00020000);
 #pragma unroll
         for (int i = 0; i < NE; i++) {
-            const int e = tid + i * NTH;
+            if (!valid[i]) continue;
+            const int unit = member * UW + ul[i], ri = ul[i] * 16 + row[i];
             float dh = pdo[i];
-            if (s > 0) dh += (red[e] + red[UW * 16 + e]) + (red[2 * UW * 16 + e] + red[3 * UW * 16 + e]);
+            if (s > 0) dh += (red[ri] + red[UW * 16 + ri]) + (red[2 * UW * 16 + ri] + red[3 * UW * 16 + ri]);
             const float gi = pg[i].x, gf = pg[i].y, gg = pg[i].z, go = pg[i].w;
             const float th = tanhf(pc[i]);
             const float dcell = dh * go * (1.f - th * th) + dcar[i];
-            float d_o = dh * th * go * (1.f - go);
-            float d_i = dcell * gg * gi * (1.f - gi);
-            float d_f = dcell * pcp[i] * gf * (1.f - gf);
-            float d_g = dcell * gi * (1.f - gg * gg);
+            const float d_o = dh * th * go * (1.f - go);
+            const float d_i = dcell * gg * gi * (1.f - gi);
+            const float d_f = dcell * pcp[i] * gf * (1.f - gf);
+            const float d_g = dcell * gi * (1.f - gg * gg);
             dcar[i] = dcell * gf;
-            if (!valid[i]) { d_i = d_f = d_g = d_o = 0.f; dcar[i] = 0.f; }
-            if (valid[i])
-                *reinterpret_cast<float4 *>(a.dg + (((size_t)t * B + brow[i]) * 2 + d) * G + unit[i] * 4) = make_float4(d_i, d_f, d_g, d_o);
+            *reinterpret_cast<float4 *>(a.dg + (((size_t)t * B + brow[i]) * 2 + d) * G + unit * 4) = make_float4(d_i, d_f, d_g, d_o);
             if (pub) {   // chunk = {hi_i hi_f | hi_g hi_o | lo_i' lo_f' | lo_g' lo_o'}: tag bit 0 rides in the even values' lo, bit 1 in the odd ones'
                 const unsigned wi = split_h(d_i), wf = split_h(d_f), wg = split_h(d_g), wo = split_h(d_o);
                 u32x4 pv;
@@ -998,7 +1015,7 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_granule_kernel(BwdPersistArgs
                 pv[1] = (wg & 0xffffu) | (wo << 16);
                 pv[2] = ((wi >> 16) | (tg & 1u)) | (((wf >> 16) | (tg >> 1)) << 16);
                 pv[3] = ((wg >> 16) | (tg & 1u)) | (((wo >> 16) | (tg >> 1)) << 16);
-                __builtin_amdgcn_raw_buffer_store_b128(pv, drs, (unsigned)((member * UW * 16 + e) * 16), 0, 16 /* sc1 */);
+                __builtin_amdgcn_raw_buffer_store_b128(pv, drs, (unsigned)(row[i] * ROWB + ((unit ^ row[i]) * 16)), 0, 16 /* sc1 */);
             }
         }
         if (s + 1 < T) prefetch(s + 1);
