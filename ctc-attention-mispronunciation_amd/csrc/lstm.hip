@@ -836,7 +836,6 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_granule_kernel(BwdPersistArgs
     constexpr int NTH = 256, UW = H / 8, UT = UW / 16, KS = H / 32, G = 4 * H;
     constexpr int ROWB = G * 4;                                     // bytes of one batch row of a panel: G/4 chunks of 16 B
     constexpr int PANB = 16 * ROWB;                                 // bytes of a panel
-    constexpr int NLD = PANB / 16 / NTH;                            // 16-byte pieces per thread for a full panel
     constexpr int NE = 16 * UW / NTH;                               // (row, unit) elements per thread in the cell backward
     static_assert(UW % 16 == 0 && (16 * UW) % NTH == 0 && PANB % (16 * NTH) == 0 && H % 32 == 0, "geometry");
     // Panel layout, in the exchange buffer and in LDS alike (the sweep is a linear copy): ROW-major, so that only the team's real rows

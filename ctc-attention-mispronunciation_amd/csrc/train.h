@@ -26,6 +26,12 @@ int launch_conv0_train_fwd(const float *x, const float *w, const float *bias, fl
 int launch_conv0_train_bwd(const float *x, const float *dz, double *acc, float *dw, float *db, int B, int T, int F, int ch, hipStream_t st);
 int launch_im2col1(const float *a0, float *col, int B, int T, int W1, int W2, int ch, hipStream_t st);
 int launch_col2im1(const float *dcol, float *da0, int B, int T, int W1, int W2, int ch, hipStream_t st);
+// conv1 as direct kernels on the channels-last activations (train_conv1.hip); ch = 32 only (other widths: im2col + GEMM)
+int launch_conv1_fwd_direct(const float *a0, const float *w1r, const float *bias, float *z1, int B, int T, int W1, int W2, int ch, hipStream_t st);
+int launch_conv1_dgrad_direct(const float *dz1, const float *w1r, float *da0, int B, int T, int W1, int W2, int ch, hipStream_t st);
+int conv1_wgrad_parts(int B, int T, int W2);
+int launch_conv1_wgrad_direct(const float *dz1, const float *a0, float *part, int B, int T, int W1, int W2, int ch, hipStream_t st);
+int init_conv1_attributes();
 int launch_pack_w1(const float *src, float *dst, int ch, bool to_packed, hipStream_t st);
 int launch_cnn_seq(float *a1, float *seq, int B, int Tp, int W2, int ch, bool to_seq, hipStream_t st);
 int launch_bn_train_fwd(const float *x, size_t R, int F, const float *gamma, const float *beta, float eps, float momentum, float *running_mean,

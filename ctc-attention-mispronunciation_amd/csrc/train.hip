@@ -199,6 +199,7 @@ extern "C" int mdd_train_create(const mdd_config *cfg, int device, mdd_train_ws 
     }
     if (int rc = init_gemm_attributes()) { delete w; return rc; }
     if (int rc = init_granule_attributes()) { delete w; return rc; }
+    if (int rc = init_conv1_attributes()) { delete w; return rc; }
     { int n_cu = 0; w->persist_ok = hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && persistent_grid_fits(n_cu) &&
                                      !(getenv("MDD_LSTM") && !strcmp(getenv("MDD_LSTM"), "step")); }
     if (8 * cfg->hidden > 8192) { delete w; set_error("mdd_train_create: hidden too large for the statistics scratch"); return MDD_ERR_ARG; }
@@ -251,7 +252,9 @@ static int train_forward_enqueue(mdd_train_ws *w, float *const *tensors, const f
     const float scale = 1.f / (1.f - p_drop), eps = c.bn_eps, mom = 0.1f;
     w->B = B; w->T = T; w->L = L; w->p_drop = p_drop; w->ids = x1_dev; w->x = x_dev;
     // ---- buffers
-    TRY(w->z0.need(R0 * ch)); TRY(w->a0.need(R0 * ch)); TRY(w->col1.need(R1 * 9 * ch)); TRY(w->w1r.need((size_t)ch * 9 * ch));
+    TRY(w->z0.need(R0 * ch)); TRY(w->a0.need(R0 * ch)); TRY(w->w1r.need((size_t)ch * 9 * ch));
+    const bool direct1 = ch == 32 && W1 <= 128 && !getenv("MDD_TRAIN_CONV1_IM2COL");   // conv1 as direct kernels (train_conv1.hip); else im2col + GEMM
+    if (!direct1) TRY(w->col1.need(R1 * 9 * ch));
     TRY(w->z1.need(R1 * ch)); TRY(w->a1.need(R1 * ch)); TRY(w->seq0.need(R * Kin0));
     TRY(w->gx.need(std::max(R, Rt) * G2)); TRY(w->hb.need((size_t)4 * B * H)); TRY(w->cb.need((size_t)2 * B * H));
     TRY(w->emb.need(Rt * E)); TRY(w->key.need(Rt * H2)); TRY(w->att.need((size_t)B * Tp * L));
@@ -299,9 +302,13 @@ static int train_forward_enqueue(mdd_train_ws *w, float *const *tensors, const f
     TRY(launch_bn_train_fwd(w->z0.p, R0, ch, P("conv.0.batch_norm.weight"), P("conv.0.batch_norm.bias"), eps, mom, P("conv.0.batch_norm.running_mean"),
                             P("conv.0.batch_norm.running_var"), w->dacc, mean, invstd, &s0, w->a0.p, st));
     // ---- conv1 (im2col + GEMM) -> BN -> ReLU -> Dropout -> [T',B,ch*W2]
-    TRY(launch_im2col1(w->a0.p, w->col1.p, B, T, W1, W2, ch, st));
     TRY(launch_pack_w1(P("conv.1.conv.weight"), w->w1r.p, ch, true, st));
-    TRY(launch_gemm_f32(false, false, w->col1.p, w->w1r.p, P("conv.1.conv.bias"), w->z1.p, (int)R1, ch, 9 * ch, 9 * ch, 9 * ch, ch, 1, 0, 0, 0, false, st));
+    if (direct1) {
+        TRY(launch_conv1_fwd_direct(w->a0.p, w->w1r.p, P("conv.1.conv.bias"), w->z1.p, B, T, W1, W2, ch, st));
+    } else {
+        TRY(launch_im2col1(w->a0.p, w->col1.p, B, T, W1, W2, ch, st));
+        TRY(launch_gemm_f32(false, false, w->col1.p, w->w1r.p, P("conv.1.conv.bias"), w->z1.p, (int)R1, ch, 9 * ch, 9 * ch, 9 * ch, ch, 1, 0, 0, 0, false, st));
+    }
     BnSite s1{w->mask_rows[1], scale};
     TRY(launch_bn_train_fwd(w->z1.p, R1, ch, P("conv.1.batch_norm.weight"), P("conv.1.batch_norm.bias"), eps, mom, P("conv.1.batch_norm.running_mean"),
                             P("conv.1.batch_norm.running_var"), w->dacc, mean + ch, invstd + ch, &s1, w->a1.p, st));
@@ -471,11 +478,21 @@ static int train_backward_enqueue(mdd_train_ws *w, float *const *tensors, const 
                             GR("conv.1.batch_norm.weight"), GR("conv.1.batch_norm.bias"), st));
     TRY(launch_col_sum(dz1, R1, ch, w->dacc, GR("conv.1.conv.bias"), st));
     TRY(w->d_b.need((size_t)ch * 9 * ch));
-    TRY(gemm_tn(w, dz1, ch, w->col1.p, 9 * ch, w->d_b.p, ch, 9 * ch, (int)R1, st));
-    TRY(launch_pack_w1(w->d_b.p, GR("conv.1.conv.weight"), ch, false, st));
-    TRY(launch_gemm_f32(false, true, dz1, w->w1r.p, nullptr, w->col1.p, (int)R1, 9 * ch, ch, ch, 9 * ch, 9 * ch, 1, 0, 0, 0, false, st));               // dcol
     float *da0 = w->d_c.p;
-    TRY(launch_col2im1(w->col1.p, da0, B, T, W1, W2, ch, st));
+    const bool direct1 = ch == 32 && W1 <= 128 && !getenv("MDD_TRAIN_CONV1_IM2COL");
+    if (direct1) {
+        const int parts = conv1_wgrad_parts(B, T, W2);
+        TRY(w->part.need((size_t)parts * ch * 9 * ch));
+        TRY(launch_conv1_wgrad_direct(dz1, w->a0.p, w->part.p, B, T, W1, W2, ch, st));
+        TRY(launch_reduce_parts(w->part.p, parts, (size_t)ch * 9 * ch, w->d_b.p, st));
+        TRY(launch_pack_w1(w->d_b.p, GR("conv.1.conv.weight"), ch, false, st));
+        TRY(launch_conv1_dgrad_direct(dz1, w->w1r.p, da0, B, T, W1, W2, ch, st));
+    } else {
+        TRY(gemm_tn(w, dz1, ch, w->col1.p, 9 * ch, w->d_b.p, ch, 9 * ch, (int)R1, st));
+        TRY(launch_pack_w1(w->d_b.p, GR("conv.1.conv.weight"), ch, false, st));
+        TRY(launch_gemm_f32(false, true, dz1, w->w1r.p, nullptr, w->col1.p, (int)R1, 9 * ch, ch, ch, 9 * ch, 9 * ch, 1, 0, 0, 0, false, st));               // dcol
+        TRY(launch_col2im1(w->col1.p, da0, B, T, W1, W2, ch, st));
+    }
     // ---- conv0
     BnSite s0{w->mask_rows[0], scale};
     float *dz0 = w->d_a.p;
