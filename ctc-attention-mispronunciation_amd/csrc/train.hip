@@ -359,7 +359,18 @@ static int train_forward_enqueue(mdd_train_ws *w, float *const *tensors, const f
     // ---- fc: BatchNorm1d(4H) -> Linear(4H -> C, no bias) -> log-softmax
     TRY(launch_bn_train_fwd(w->cat.p, R, 2 * H2, P("fc.0.weight"), P("fc.0.bias"), eps, mom, P("fc.0.running_mean"), P("fc.0.running_var"), w->dacc,
                             mean + 2 * ch + nl * H2, invstd + 2 * ch + nl * H2, nullptr, w->ycat.p, st));
-    TRY(launch_gemm_f32(false, false, w->ycat.p, P("fc.1.weight"), nullptr, w->logits.p, (int)R, C, 2 * H2, 2 * H2, 2 * H2, C, 1, 0, 0, 0, false, st));
+    {   // [R, 1536] x [45, 1536]^T: one column tile, 63 row tiles at R = 8000 -> the contraction is cut into partial products so the chip is busy
+        const int Kfc = 2 * H2, tiles = (int)((R + 127) / 128) * ((C + 127) / 128);
+        const int ks = (tiles < 128 && Kfc >= 1024) ? 256 : 0;
+        if (ks) {
+            const int parts = (Kfc + ks - 1) / ks;
+            TRY(w->part.need((size_t)parts * R * C));
+            TRY(launch_gemm_f32(false, false, w->ycat.p, P("fc.1.weight"), nullptr, w->part.p, (int)R, C, Kfc, Kfc, Kfc, C, 1, 0, 0, (long)R * C, false, st, ks));
+            TRY(launch_reduce_parts(w->part.p, parts, R * C, w->logits.p, st));
+        } else {
+            TRY(launch_gemm_f32(false, false, w->ycat.p, P("fc.1.weight"), nullptr, w->logits.p, (int)R, C, Kfc, Kfc, Kfc, C, 1, 0, 0, 0, false, st));
+        }
+    }
     TRY(launch_softmax_rows(w->logits.p, R, C, w->logp.p, true, st));
     MDD_HIP_CHECK(hipMemcpyAsync(logp_dev, w->logp.p, R * C * sizeof(float), hipMemcpyDeviceToDevice, st));
     return MDD_OK;
