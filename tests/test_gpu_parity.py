@@ -880,6 +880,39 @@ def test_train_variant_soak_and_eval_consistency():
     assert torch.isfinite(ev).all() and float(torch.exp(ev.double()).sum(-1).sub(1).abs().max()) < 1e-5
 
 
+def test_train_variant_tracks_exact_mode_over_steps():
+    """The same 25 optimizer steps (same initial weights, batch, seeded dropout draws) in exact fp32 and in the flagged split-bf16 variant:
+    the two loss curves stay within 1 % of the initial loss of each other over the first ten steps (5 % to the end, where the batch is being
+    memorised and the trajectories are sensitive to any rounding) and both fall below a tenth of it."""
+    from ctc_attention_mispronunciation_amd.train import CTCLoss, Adam
+    geom = synth.Geometry(**synth.REFERENCE)
+    B, T, L = 16, 64, 8
+    sd, x, x1, _, tg, il, tl = synth.train_case(geom, 21, B, T, L, 5)
+    xd, x1d = _cuda(x), _cuda(x1)
+    tgd, ild, tld = torch.from_numpy(tg), torch.from_numpy(il), torch.from_numpy(tl)
+    curves = {}
+    for mode in ("f32", "bf16x3"):
+        model = _train_model(geom, sd)
+        model.train_precision = mode
+        opt = Adam(model.parameters(), lr=1e-3, weight_decay=5e-4)
+        crit = CTCLoss(reduction="sum")
+        torch.manual_seed(1234)
+        cur = []
+        for _ in range(25):
+            out = model(xd, x1d)
+            loss = crit(out, tgd, ild, tld) / B
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+            cur.append(float(loss.detach()))
+        curves[mode] = np.asarray(cur)
+    print("f32   ", np.round(curves["f32"], 3))
+    print("bf16x3", np.round(curves["bf16x3"], 3))
+    rel = np.abs(curves["bf16x3"] - curves["f32"]) / curves["f32"][0]      # against the initial loss: the end of the curves is a memorised batch
+    assert rel[:10].max() < 1e-2 and rel.max() < 5e-2
+    assert curves["f32"][-1] < 0.1 * curves["f32"][0] and curves["bf16x3"][-1] < 0.1 * curves["bf16x3"][0]
+
+
 def test_run_epoch_mirror_trains_and_validates():
     """steps/train_ctc.run_epoch (the reference's loop, train_ctc.py:28-105) over an in-memory loader of create_input batches:
     a training epoch then a validation epoch; returns (accuracy, mean loss), parameters move only in training."""
