@@ -52,6 +52,8 @@ int launch_lstm_bwd(const LstmBwdArgs &a, hipStream_t st);
 int launch_lstm_layer_train(const LstmStepArgs &a, hipStream_t st);   // lstm.hip: generic step kernels, saving gates and cell states
 int launch_split_rows(const float *src, int ld, size_t rows, int cols, int cols_pad, unsigned short *hi, unsigned short *lo, hipStream_t st);
 int launch_transpose_split(const float *src, int ld, int rows, int cols, int rows_pad, unsigned short *hi, unsigned short *lo, hipStream_t st);
+int launch_adam_multi(float *const *p, float *const *g, float *const *m, float *const *v, const int64_t *numel, int n, float lr, float b1, float b2, float eps,
+                      float wd, int step, hipStream_t st);
 int launch_adam(float *p, const float *g, float *m, float *v, size_t n, float lr, float b1, float b2, float eps, float wd, int step, hipStream_t st);
 
 }  // namespace mdd

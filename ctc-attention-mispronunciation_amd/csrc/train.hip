@@ -529,9 +529,7 @@ extern "C" int mdd_train_sync(mdd_train_ws *w, void *stream) {
 extern "C" int mdd_adam_step(float *const *params, float *const *grads, float *const *exp_avg, float *const *exp_avg_sq, const int64_t *numel, int32_t n,
                              int32_t step, float lr, float beta1, float beta2, float eps, float weight_decay, void *stream) {
     if (!params || !grads || !exp_avg || !exp_avg_sq || !numel || n < 0 || step < 1) { set_error("mdd_adam_step: bad argument"); return MDD_ERR_ARG; }
-    for (int i = 0; i < n; i++) {
-        if (!params[i] || !grads[i] || numel[i] <= 0) continue;
-        TRY(launch_adam(params[i], grads[i], exp_avg[i], exp_avg_sq[i], (size_t)numel[i], lr, beta1, beta2, eps, weight_decay, step, (hipStream_t)stream));
-    }
-    return MDD_OK;
+    for (int i = 0; i < n; i++)
+        if (params[i] && grads[i] && numel[i] > 0 && (!exp_avg[i] || !exp_avg_sq[i])) { set_error("mdd_adam_step: state of tensor %d missing", i); return MDD_ERR_ARG; }
+    return launch_adam_multi(params, grads, exp_avg, exp_avg_sq, numel, n, lr, beta1, beta2, eps, weight_decay, step, (hipStream_t)stream);
 }

@@ -773,4 +773,47 @@ int launch_adam(float *p, const float *g, float *m, float *v, size_t n, float lr
     return MDD_OK;
 }
 
+// The same update over up to 48 tensors in ONE launch (the model has 55 parameter tensors, most of them small: one launch each was a
+// quarter millisecond of launches per step).  The table travels in the kernel arguments; workgroup w works on 1024-element chunk
+// w - first[t] of tensor t (first[] = running chunk counts).
+constexpr int ADAM_MT = 48;
+struct AdamTable { float *p[ADAM_MT]; const float *g[ADAM_MT]; float *m[ADAM_MT]; float *v[ADAM_MT]; unsigned long long n[ADAM_MT]; int first[ADAM_MT + 1]; int count; };
+__global__ __launch_bounds__(256) void adam_multi_kernel(AdamTable tb, float lr, float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt) {
+    int t = 0;
+    while (t + 1 < tb.count && (int)blockIdx.x >= tb.first[t + 1]) t++;            // (uniform per workgroup; <= 48 steps)
+    const size_t i0 = (size_t)((int)blockIdx.x - tb.first[t]) * 1024;
+    float *p = tb.p[t], *m = tb.m[t], *v = tb.v[t];
+    const float *g = tb.g[t];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const size_t i = i0 + threadIdx.x + 256 * k;
+        if (i < tb.n[t]) {
+            const float gi = g[i] + wd * p[i];
+            const float mi = b1 * m[i] + (1.f - b1) * gi;
+            const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+            m[i] = mi; v[i] = vi;
+            p[i] -= (lr / bc1) * (mi / (sqrtf(vi) / bc2_sqrt + eps));
+        }
+    }
+}
+int launch_adam_multi(float *const *p, float *const *g, float *const *m, float *const *v, const int64_t *numel, int n, float lr, float b1, float b2, float eps,
+                      float wd, int step, hipStream_t st) {
+    const float bc1 = 1.f - powf(b1, (float)step), bc2s = sqrtf(1.f - powf(b2, (float)step));
+    int i = 0;
+    while (i < n) {
+        AdamTable tb;
+        tb.count = 0; tb.first[0] = 0;
+        for (; i < n && tb.count < ADAM_MT; i++) {
+            if (!p[i] || !g[i] || numel[i] <= 0) continue;
+            const int c = tb.count++;
+            tb.p[c] = p[i]; tb.g[c] = g[i]; tb.m[c] = m[i]; tb.v[c] = v[i]; tb.n[c] = (unsigned long long)numel[i];
+            tb.first[c + 1] = tb.first[c] + (int)((numel[i] + 1023) / 1024);
+        }
+        if (tb.count == 0) break;
+        hipLaunchKernelGGL(adam_multi_kernel, dim3((unsigned)tb.first[tb.count]), dim3(256), 0, st, tb, lr, b1, b2, eps, wd, bc1, bc2s);
+        MDD_LAUNCH_CHECK();
+    }
+    return MDD_OK;
+}
+
 }  // namespace mdd
