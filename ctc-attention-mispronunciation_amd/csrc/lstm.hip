@@ -617,6 +617,7 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_granule_kernel(PersistArgs 
                 const bool early = PF != 0 && a.early && ns < T;
                 if (early) { request_sweep(nbt, ns, pb ^ 1); requested = true; }
                 const bool do_gx = s + 1 < T, do_rq = PF == 2 && ns < T && !early;
+                const int tt_next = d ? max(T - 2 - s, 0) : min(s + 1, T - 1);   // the step whose slab this phase requests
                 // The MFMA operands come straight from the travelling chunks (no unpacking pass, no second copy in LDS): per
                 // k-step two 16-byte chunks {hi x4 | lo' x4} -> the hi halves of both are one operand, the lo halves (tag
                 // bits cleared: 4 v_and) the other.  One tagged word per chunk is summed on the way (bit 0 and bit 16
@@ -648,8 +649,12 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_granule_kernel(PersistArgs 
                         lq[0] = xa[2] & 0xfffefffeu; lq[1] = xa[3] & 0xfffefffeu; lq[2] = xb[2] & 0xfffefffeu; lq[3] = xb[3] & 0xfffefffeu;
                         if (PF != 0) { sraw += xa[2] + xb[2]; smask += lq[0] + lq[2]; }   // one tagged word per 16-byte chunk: a chunk is one lane's single store
                         const bf16x8 bh = __builtin_bit_cast(bf16x8, hq), bl = __builtin_bit_cast(bf16x8, lq);
-                        if (tries == 0) {
-                            if (ks < NGX) { if (do_gx) load_gx(bt, (s + 1) & 1, d ? (T - 2 - s) : (s + 1), ks, ks + 1); }
+                        // One and two tiles: the slab pieces are issued unconditionally (a branch per k-step costs the loop more than the
+                        // piece: -2.6 % on the product section): at the last step they fetch a valid slab nobody reads, in a redo they fetch
+                        // the same slab again.  (Three and four tiles keep the guarded form: their sweep pieces share these k-steps.)
+                        if (PF != 2) { if (ks < NGX) load_gx(bt, (s + 1) & 1, tt_next, ks, ks + 1); }
+                        else if (tries == 0) {
+                            if (ks < NGX) { if (do_gx) load_gx(bt, (s + 1) & 1, tt_next, ks, ks + 1); }
                             else if (ks < NGX + NLD) { if (do_rq) request_sweep(nbt, ns, pb ^ 1, ks - NGX, ks - NGX + 1); }
                         }
                         // product-major order: consecutive MFMAs hit different accumulators (no dependent-issue stall);
@@ -684,8 +689,9 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_granule_kernel(PersistArgs 
                 }
                 if (a.dbg && PF != 0) ph[5] += 1;
                 if (do_rq) requested = true;
-                int in_flight = tries ? 0 : ((do_gx ? NGX : 0) + ((do_rq || early) ? NLD : 0));
-                early_gx = (early && do_gx && !tries) ? NGX : 0;       // memory instructions younger than an early request
+                int in_flight = PF != 2 ? NGX + ((early && !tries) ? NLD : 0)       // (a redo's vmcnt(0) came before its own slab pieces)
+                                        : (tries ? 0 : ((do_gx ? NGX : 0) + ((do_rq || early) ? NLD : 0)));
+                early_gx = (early && (PF != 2 || do_gx) && !tries) ? NGX : 0;       // memory instructions younger than an early request
                 if (PF == 1 && ns < T && !early) {   // two tiles: the other tile's panel has had the length of these MFMAs to arrive
                     request_sweep(nbt, ns, pb ^ 1); requested = true;
                     in_flight += NLD;
