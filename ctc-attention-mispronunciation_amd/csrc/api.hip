@@ -84,7 +84,10 @@ struct mdd_model {
     unsigned int *sync_words = nullptr;
     bool lstm_x3 = false;   // MDD_LSTM=x3: LDS-tiled split-bf16 step kernel (measured slower than the packed fp32 step; kept for study)
     bool conv_fused() const { return x3() && cfg.feat == 243 && cfg.channels == 32; }
-    bool persist(int B) const { return x3() && lstm_persist && !lstm_x3 && B <= granule_max_b; }
+    bool packed_h() const { return cfg.hidden == 384 || cfg.hidden == 256; }
+    // one persistent launch per BiLSTM layer: the split-bf16 teams (lstm.hip) in mode 1, the exact-fp32 teams (lstm_f32.hip) in mode 0
+    bool persist(int B) const { return lstm_persist && !lstm_x3 && packed_h() && B <= granule_max_b && (x3() || lstm_persist_f32); }
+    bool lstm_persist_f32 = true;
     bool x3() const {   // the bf16x3 GEMM needs K % 32 == 0 for every contraction and the packed LSTM layouts
         return precision == 1 && (cfg.hidden == 384 || cfg.hidden == 256) && rnn_in() % 32 == 0 && cfg.emb_dim % 32 == 0;
     }
@@ -255,7 +258,11 @@ static int run_stage(mdd_model *m, int si, const float *x, int B, int T, const i
             a.out_split = x3 ? split_view(m->act_s[n & 1], rows * H2) : kNoSplit;
             a.oscale = m->bn_scale[n + 1]; a.oshift = m->bn_shift[n + 1];
         }
-        if (m->persist(B)) { info->launches = 1; return launch_lstm_layer_granule(a, reinterpret_cast<unsigned short *>(m->hx.p), m->sync_words, m->err_flag, st); }
+        if (m->persist(B)) {
+            info->launches = 1;
+            return x3 ? launch_lstm_layer_granule(a, reinterpret_cast<unsigned short *>(m->hx.p), m->sync_words, m->err_flag, st)
+                      : launch_lstm_layer_f32(a, reinterpret_cast<unsigned short *>(m->hx.p), m->sync_words, m->err_flag, st);
+        }
         return launch_lstm_layer(a, st);
     }
     si -= 2 * nl;
@@ -278,7 +285,11 @@ static int run_stage(mdd_model *m, int si, const float *x, int B, int T, const i
         a.T = L; a.B = B; a.H = H; a.packed = use_packed(m);
         a.whh_split = m->t_whh_s; a.hsplit = (x3 && m->lstm_x3) ? reinterpret_cast<unsigned short *>(m->hsplit.p) : nullptr;
         a.seqlen = m->llen;
-        if (m->persist(B)) { info->launches = 1; return launch_lstm_layer_granule(a, reinterpret_cast<unsigned short *>(m->hx.p), m->sync_words, m->err_flag, st); }
+        if (m->persist(B)) {
+            info->launches = 1;
+            return x3 ? launch_lstm_layer_granule(a, reinterpret_cast<unsigned short *>(m->hx.p), m->sync_words, m->err_flag, st)
+                      : launch_lstm_layer_f32(a, reinterpret_cast<unsigned short *>(m->hx.p), m->sync_words, m->err_flag, st);
+        }
         return launch_lstm_layer(a, st);
     }
     case 3:
@@ -372,10 +383,12 @@ extern "C" int mdd_create(const mdd_config *cfg, int device, mdd_model **out) {
     if (int rc = init_kernel_attributes()) { delete m; return rc; }
     if (int rc = init_lstm_attributes()) { delete m; return rc; }
     if (int rc = init_granule_attributes()) { delete m; return rc; }
+    if (int rc = init_lstm_f32_attributes()) { delete m; return rc; }
     if (int rc = init_conv_attributes()) { delete m; return rc; }
     if (int rc = init_gemm_attributes()) { delete m; return rc; }
     m->n_cu = prop.multiProcessorCount;
     if (!persistent_grid_fits(m->n_cu)) m->lstm_persist = false;   // per-step kernels instead (smaller partitions, other gfx950 SKUs)
+    if (!persistent_f32_grid_fits(m->n_cu)) m->lstm_persist_f32 = false;
     hipError_t e = hipMalloc((void **)&m->err_flag, sizeof(int));
     if (e == hipSuccess) e = hipMemset(m->err_flag, 0, sizeof(int));
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&m->cap_stream, hipStreamNonBlocking);
@@ -554,9 +567,9 @@ static int forward_prepare(mdd_model *m, const float *x_dev, int32_t B, int32_t 
     if (m->x3() && ((rc = ensure(m->seq0_s, rows * m->rnn_in(), zs)) || (rc = ensure(m->act_s[0], rows * 2 * H, zs)) ||
                     (rc = ensure(m->act_s[1], rows * 2 * H, zs)) || (rc = ensure(m->x_s, rows * 2 * H, zs)) ||
                     (rc = ensure(m->embo_s, trows * c.emb_dim, zs)) || (rc = ensure(m->text_s, trows * 2 * H, zs)) ||
-                    (rc = ensure(m->key_s, trows * 2 * H, zs)) || (rc = ensure(m->hsplit, (size_t)4 * B * H, zs)) ||
-                    (rc = ensure(m->hx, (size_t)2 * 32 * granule_bg(B) * H * 2 + 64 + 256 * 6 * 2, zs))))   // u64 granules + stamps
+                    (rc = ensure(m->key_s, trows * 2 * H, zs)) || (rc = ensure(m->hsplit, (size_t)4 * B * H, zs))))
         return rc;
+    if (m->persist(B) && (rc = ensure(m->hx, (size_t)2 * 32 * granule_bg(B) * H * 2 + 64 + 256 * 6 * 2, zs))) return rc;   // the exchange buffer of the persistent layers (u64 granules) + stamps
     if (m->taps) {
         m->tap_rnn.resize(c.layers);
         for (int n = 0; n + 1 < c.layers; n++) if ((rc = ensure(m->tap_rnn[n], rows * 2 * H, zs))) return rc;

@@ -16,13 +16,10 @@
 //
 // The launch boundary is the step-to-step dependency (all-to-all over hidden units): per the
 // MI355X price list a dependent kernel boundary (~1.5 us) is cheaper than any in-launch grid sync.
-#include "mdd_internal.h"
+#include "lstm_persist.h"
 
 namespace mdd {
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-__device__ __forceinline__ float sigmoid_f(float v) { return 1.f / (1.f + expf(-v)); }
 // split-bf16 kernels: hardware exp2 / rcp (<= ~2 ulp each; |error| on a gate <= 3e-7, far below the 1e-5 the bf16x3
 // products already spend of the 1e-4 budget).  The exact-fp32 mode keeps the libm-grade functions above.
 __device__ __forceinline__ float fast_sigmoid(float v) { return __builtin_amdgcn_rcpf(1.f + __expf(-v)); }
@@ -111,8 +108,9 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(LstmStepArgs a, int s) {
 // and h is exchanged between steps in the same consumer order,
 //   hp[parity][d][bt][j][lane][m] = h[bt*16 + (lane&15)][16 j + 4 (lane>>4) + m]
 // (a producer wave owns k = 4 ut .. 4 ut+3 for 16 batch rows: 64 contiguous floats), and c lives in
-// producer order cp[d][bt][ut][lane].  Four independent accumulators (one per float4 component) keep
-// the MFMA pipe at its 32-cycle issue rate instead of the 40-cycle dependent latency.
+// producer order cp[d][bt][ut][lane].  Two independent accumulators (even / odd float4 components) keep
+// the MFMA pipe at its 32-cycle issue rate instead of the 40-cycle dependent latency; lstm_layer_f32_kernel (lstm_f32.hip)
+// repeats this accumulation order and the cell update bit for bit.
 template <int J>
 __global__ __launch_bounds__(256, 1) void lstm_step_packed_kernel(LstmStepArgs a, int s) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -135,7 +133,7 @@ __global__ __launch_bounds__(256, 1) void lstm_step_packed_kernel(LstmStepArgs a
         g4 = *reinterpret_cast<const float4 *>(a.gx + (((size_t)t * B + b) * 2 + d) * 4 * H + u * 4);
         if (s > 0) cold = a.cbuf[ci];
     }
-    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0, acc2 = acc0, acc3 = acc0;
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
     if (s > 0) {
         float4 w4[J], h4[J];
 #pragma unroll
@@ -147,19 +145,19 @@ __global__ __launch_bounds__(256, 1) void lstm_step_packed_kernel(LstmStepArgs a
         for (int j = 0; j < J; j++) {
             acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w4[j].x, h4[j].x, acc0, 0, 0, 0);
             acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w4[j].y, h4[j].y, acc1, 0, 0, 0);
-            acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(w4[j].z, h4[j].z, acc2, 0, 0, 0);
-            acc3 = __builtin_amdgcn_mfma_f32_16x16x4f32(w4[j].w, h4[j].w, acc3, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w4[j].z, h4[j].z, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w4[j].w, h4[j].w, acc1, 0, 0, 0);
         }
     }
     if (b < B) {
-        const float gi = (acc0[0] + acc1[0]) + (acc2[0] + acc3[0]) + g4.x;
-        const float gf = (acc0[1] + acc1[1]) + (acc2[1] + acc3[1]) + g4.y;
-        const float gg = (acc0[2] + acc1[2]) + (acc2[2] + acc3[2]) + g4.z;
-        const float go = (acc0[3] + acc1[3]) + (acc2[3] + acc3[3]) + g4.w;
-        const float ig = sigmoid_f(gi), fg = sigmoid_f(gf), cg = tanhf(gg), og = sigmoid_f(go);
+        const float gi = (acc0[0] + acc1[0]) + g4.x;
+        const float gf = (acc0[1] + acc1[1]) + g4.y;
+        const float gg = (acc0[2] + acc1[2]) + g4.z;
+        const float go = (acc0[3] + acc1[3]) + g4.w;
+        const float ig = gate_sigmoid(gi), fg = gate_sigmoid(gf), cg = gate_tanh(gg), og = gate_sigmoid(go);
         const bool hold = d && a.seqlen && t >= a.seqlen[b];
         const float cn = hold ? 0.f : fg * cold + ig * cg;
-        const float hn = hold ? 0.f : og * tanhf(cn);
+        const float hn = hold ? 0.f : og * gate_tanh(cn);
         a.cbuf[ci] = cn;
         float *hnext = a.hbuf + (s & 1) * hplane;
         hnext[(((size_t)(d * NBT + bt) * J + (ut >> 2)) * 64 + (ut & 3) * 16 + li) * 4 + uu] = hn;
@@ -186,7 +184,6 @@ __global__ __launch_bounds__(256, 1) void lstm_step_packed_kernel(LstmStepArgs a
 // (the producer lane writes its bf16 pair), c stays fp32 row-major.
 // LDS: Wh | Wl : RT*16 rows, hh | hl : 64 rows, each row H*2 bytes + 16 pad (conflict-free ds_read_b128 fragments).
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 // The recurrent state as split bf16: hi = bf16(h), lo = bf16(h - hi) with its last mantissa bit cleared.  Every
 // recurrent kernel (per-step and persistent) uses this same split, so they stay bit-identical; the cleared bit is where
@@ -321,27 +318,8 @@ int init_lstm_attributes() {
 // fused batch sizes the step is bound by that re-read.  The persistent form keeps every workgroup's W_hh rows in registers for
 // the whole layer and moves only h between the workgroups of a team.  (An earlier form of it -- 16-workgroup teams around a
 // per-team arrival counter -- was superseded by the data-tagged hand-off and is no longer built.)
-struct PersistArgs {
-    const float *gx;                 // [T][B][2][4H] permuted gate columns
-    SplitPtr whh;                    // Whh' [2][4H][H] row-major hi/lo
-    unsigned short *hx;              // [2 parity][32 teams][tiles][H/4 chunk columns][16 rows] x 16 B: tagged chunks of the state in flight
-    unsigned int *sync;              // [16] unused, [16] abort flag  (zeroed before every launch)
-    int *err_flag;
-    float *out, *out_raw;
-    SplitPtr out_split;
-    const float *oscale, *oshift;
-    int T, B, BG, BGr;               // BG: padded rows per group (multiple of 16), BGr: real rows per group
-    long long *dbg;                  // diagnostic builds only: per-workgroup cycle sums of the step phases (null in production)
-    const int *seqlen;               // see LstmStepArgs::seqlen (null = every row runs all T steps)
-    float *gates_save, *c_save;      // TRAIN instantiations: post-activation i,f,g,o [T][B][2][H][4] and c_t [T][B][2][H] for the backward pass
-    int early;                       // diagnostic (MDD_LSTM_EARLY): request the next tile's panel a whole MFMA section too early, so that stale panels and the redo path occur
-};
 
-typedef unsigned long long u64;
-typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
-// diagnostic phase stamps (MDD_LSTM_DBG): cycle sums per phase of the step, read by tools/lstm_stamps.py
-#define PSTAMP(i) do { if (a.dbg) { long long n_ = __builtin_readcyclecounter(); ph[i] += n_ - tst; tst = n_; } } while (0)
 
 // acc += A.B with A taken straight from an accumulation-file register (half of the resident weight fragments live
 // there: the compiler would otherwise copy each one to a VGPR with four v_accvgpr_read per MFMA, on every step)
@@ -371,48 +349,6 @@ __device__ __forceinline__ void mfma_a(f32x4 &acc, const bf16x8 &a_agpr, const b
 // after the MFMAs of the phase before (the panel is not complete earlier); with one there is nothing to overlap.
 // The gate pre-activations never occupy registers: each tile's next [16 rows x 4*UW] slab is fetched by LDS-DMA as
 // soon as the cell update has consumed the current one.
-typedef __attribute__((address_space(3))) void lds_void_t;
-
-// Workgroup barrier that orders LDS traffic only.  __syncthreads() carries a workgroup-scope release fence, which on
-// gfx950 is s_waitcnt vmcnt(0): every barrier would drain the write-through publish stores, the output stores and the
-// in-flight LDS-DMA / sweep requests this kernel deliberately keeps outstanding across phases.  Global memory needs no
-// ordering here (the hand-off is data-tagged); where an LDS-DMA result must be visible, an explicit s_waitcnt vmcnt(N)
-// precedes the barrier.
-__device__ __forceinline__ void wait_vmcnt(int n) {   // s_waitcnt vmcnt(n) for a wave-uniform n (the count is an immediate)
-    switch (n) {
-        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-        case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
-        case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
-        case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
-        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
-        case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
-        case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
-        case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
-        case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
-        default: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;   // n >= 9: waiting for more than asked is always safe
-    }
-}
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-// One LDS-DMA instruction (64 lanes x 16 bytes -> 1 KB lane-linear at the wave-uniform LDS address l), written as
-// inline assembly on purpose: the compiler's wait-count pass treats the builtin form as an LDS write still in flight
-// and puts s_waitcnt vmcnt(0) in front of the next LDS read it can relate to it -- here the cell update's slab read and
-// the staged sweep's read-back -- which also waits for every store issued in between (the write-through publish alone
-// takes ~1 us to acknowledge) and for the sweep request the kernel wants in flight during the cell update.  All waits
-// on these transfers are the explicit counted ones below.
-// Same, with the global address as a wave-uniform base (SGPR pair) plus a 32-bit per-lane byte offset and the LDS
-// address already scalar: no 64-bit vector address arithmetic per piece.
-template <bool SC1>
-__device__ __forceinline__ void lds_dma16_s(const void *sbase, unsigned voff, unsigned la) {
-    if (SC1) asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 sc1" :: "v"(voff), "s"(sbase), "s"(la) : "memory", "m0");
-    else asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(voff), "s"(sbase), "s"(la) : "memory", "m0");
-}
-template <bool SC1>
-__device__ __forceinline__ void lds_dma16(const void *g, void *l) {
-    const unsigned la = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)(lds_void_t *)l);
-    if (SC1) asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off sc1" :: "v"(g), "s"(la) : "memory", "m0");
-    else asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(g), "s"(la) : "memory", "m0");
-}
-
 template <int H, int NBT, int RTW, bool TRAIN = false>
 __global__ __launch_bounds__(256, 1) void lstm_layer_granule_kernel(PersistArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -773,7 +709,6 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_granule_kernel(PersistArgs 
 
 int granule_bg(int B) { const int r = (B + 15) / 16; return (r + 15) / 16 * 16; }   // rows per batch group (16 groups), padded to whole tiles
 
-static constexpr int kPersistGrid = 256;   // see persistent_grid_fits()
 
 template <int H, int NBT, int RTW, bool TRAIN = false>
 static int launch_granule_t(PersistArgs a, hipStream_t st) {
@@ -787,7 +722,7 @@ static int launch_granule_t(PersistArgs a, hipStream_t st) {
 
 int launch_lstm_layer_granule(const LstmStepArgs &s, unsigned short *hx, unsigned int *sync, int *err_flag, hipStream_t st) {
     PersistArgs a;
-    a.gx = s.gx; a.whh = s.whh_split; a.hx = hx; a.sync = sync; a.err_flag = err_flag;
+    a.gx = s.gx; a.whh = s.whh_split; a.whh_f32 = nullptr; a.hx = hx; a.sync = sync; a.err_flag = err_flag;
     a.out = s.out; a.out_raw = s.out_raw; a.out_split = s.out_split; a.oscale = s.oscale; a.oshift = s.oshift;
     a.T = s.T; a.B = s.B; a.BGr = (s.B + 15) / 16; a.BG = granule_bg(s.B); a.seqlen = s.seqlen;
     a.dbg = (getenv("MDD_LSTM_DBG") && s.T > 100) ? reinterpret_cast<long long *>(reinterpret_cast<u64 *>(hx) + (size_t)2 * 32 * a.BG * s.H) : nullptr;

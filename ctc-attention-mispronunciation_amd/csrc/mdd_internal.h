@@ -97,6 +97,10 @@ int init_granule_attributes();
 int persistent_grid_fits(int n_cu);   // 1 when all 256 workgroups of a persistent layer launch can be resident at once
 // data-tagged variant (8-workgroup teams, no counter): hx = 2*32*granule_bg(B)*H u64 granules (+ stamps), sync: 32 uints
 int launch_lstm_layer_granule(const LstmStepArgs &s, unsigned short *hx, unsigned int *sync, int *err_flag, hipStream_t st);
+// Exact-fp32 persistent layer (lstm_f32.hip): same teams / exchange buffer; W_hh in the packed layout (LstmStepArgs::packed), fp32 outputs
+int launch_lstm_layer_f32(const LstmStepArgs &s, unsigned short *hx, unsigned int *sync, int *err_flag, hipStream_t st);
+int init_lstm_f32_attributes();
+int persistent_f32_grid_fits(int n_cu);
 // The backward recurrence of a layer in one launch (split-bf16 training variant, B <= 256, H in {256, 384}); hx: lstm_bwd_granule_hx_bytes(H)
 size_t lstm_bwd_granule_hx_bytes(int H);
 int launch_lstm_bwd_granule(const float *dout, const float *gates, const float *cst, SplitPtr whhT, float *dg, int T, int B, int H, unsigned short *hx,

@@ -67,11 +67,17 @@ int mdd_load_weight(mdd_model *m, const char *key, const float *data, const int6
  * repack LSTM gate rows for the step kernel.  Synchronises the device. */
 int mdd_finalize_weights(mdd_model *m);
 
-/* Arithmetic of the time-batched contractions (BiLSTM input projections, text projection, `score`, attention
- * scores): 0 = exact fp32 on v_mfma_f32_32x32x2_f32; 1 (default) = split-bf16 "x3" on v_mfma_f32_32x32x16_bf16
- * (each fp32 operand = bf16 hi + bf16 lo, products hi.hi + hi.lo + lo.hi, fp32 accumulate; measured effect on the
- * log-probs <= 1e-5, tolerance 1e-4).  Mode 1 falls back to 0 when a contraction length is not a multiple of 32.
- * Env MDD_PRECISION=f32 selects mode 0 at mdd_create.  mdd_get_precision returns the mode actually in use. */
+/* Arithmetic of the model's contractions.
+ * 0 = reference width: every product is an exact fp32 MFMA (v_mfma_f32_32x32x2_f32 in the time-batched GEMMs,
+ *     v_mfma_f32_16x16x4_f32 in the recurrent W_hh.h products and the convolutions), fp32 accumulate -- the arithmetic of
+ *     the reference's ATen fp32 ops (AA/models/model_ctc.py:27-29,59-66,149-158).
+ * 1 = split-bf16 "x3" on v_mfma_f32_16x16x32_bf16: each fp32 operand = bf16 hi + bf16 lo (~16 significand bits),
+ *     products hi.lo + lo.hi + hi.hi, fp32 accumulate.  This covers EVERY contraction of the forward: conv0 / conv1, the
+ *     BiLSTM input projections, the recurrent W_hh.h products (h is re-split every step), the text projection, `score`
+ *     and the attention scores; cell state, gates, softmax and the classifier tail stay fp32.  Measured effect on the
+ *     log-probs <= 1e-5 (tolerance 1e-4).  Narrower than the reference's arithmetic: a flagged variant.
+ *     Mode 1 falls back to 0 when a contraction length is not a multiple of 32 or the hidden size is not 256 / 384.
+ * Env MDD_PRECISION=f32 / bf16x3 selects the mode at mdd_create.  mdd_get_precision returns the mode actually in use. */
 int mdd_set_precision(mdd_model *m, int32_t mode);
 int32_t mdd_get_precision(mdd_model *m);
 
@@ -220,6 +226,9 @@ int mdd_adam_step(float *const *params, float *const *grads, float *const *exp_a
  * kernel once and the 8-phase kernel (both DMA placements) `reps` times each; *mismatches_out = C words that ever
  * differed (must be 0; tests/test_gpu_parity.py::test_gemm_8phase_race_screen).  ms_out (nullable, 16 floats): mean kernel times. */
 int mdd_diag_gemm_ph8(int M, int N, int K, int reps, unsigned seed, unsigned *mismatches_out, float *ms_out);
+/* mdd_diag_gates: the gate nonlinearities of the reference-width recurrences (csrc/lstm_persist.h) evaluated on n device floats:
+ * sig_dev[i] = sigmoid(x_dev[i]), tanh_dev[i] = tanh(x_dev[i]) (tests/test_gpu_parity.py::test_gate_functions_accuracy). */
+int mdd_diag_gates(const float *x_dev, float *sig_dev, float *tanh_dev, int64_t n, void *stream);
 
 #ifdef __cplusplus
 }

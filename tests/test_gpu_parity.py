@@ -263,6 +263,88 @@ def test_persistent_lstm_batch_sizes_match_step_kernels(B, H, monkeypatch):
     np.testing.assert_array_equal(got, ref)
 
 
+@pytest.mark.parametrize("H", [384, 256])
+@pytest.mark.parametrize("B", [17, 100, 256, 300, 512, 513, 700, 1000, 1024])
+def test_persistent_f32_lstm_batch_sizes_match_step_kernels(B, H, monkeypatch):
+    """The reference-width persistent BiLSTM (lstm_layer_f32_kernel: exact fp32 MFMA, W_hh resident in registers) in every team
+    geometry (1 to 4 row tiles per team), H = 384 and H = 256, against one lstm_step_packed_kernel launch per step: bit for bit,
+    taps of every layer included; ragged lengths exercise the reverse direction's per-row start."""
+    geom = synth.Geometry(**dict(synth.REFERENCE, hidden=H))
+    sd = synth.synth_state_dict(geom, seed=77)
+    x, x1, _, _ = synth.synth_batch(geom, B=B, T=40, L=6, seed=B, ragged=True)
+    monkeypatch.setenv("MDD_LSTM", "step")
+    m0 = _hip().HipModel(geom, sd, precision="f32", taps=True)
+    ref = m0.forward(_cuda(x), _cuda(x1), sync_errors=True).cpu().numpy()
+    ref_taps = [m0.tap("rnn%d" % i).cpu().numpy() for i in range(4)] + [m0.tap("text").cpu().numpy()]
+    monkeypatch.delenv("MDD_LSTM")
+    m1 = _hip().HipModel(geom, sd, precision="f32", taps=True)
+    got = m1.forward(_cuda(x), _cuda(x1), sync_errors=True).cpu().numpy()
+    for i, name in enumerate(["rnn0", "rnn1", "rnn2", "rnn3", "text"]):
+        np.testing.assert_array_equal(m1.tap(name).cpu().numpy(), ref_taps[i], err_msg=name)
+    np.testing.assert_array_equal(got, ref)
+
+
+def test_persistent_f32_lstm_full_length_and_poisoned_input(monkeypatch):
+    """T' = 250 at the benchmarked batch (two row tiles per team) against the step kernels, bit for bit; then one utterance gets a NaN
+    and an Inf frame: the launch neither stalls nor reports an error (the tagged hand-off keeps valid tags whatever the state holds),
+    and every other utterance's rows are untouched."""
+    geom = synth.Geometry(**synth.REFERENCE)
+    sd = synth.synth_state_dict(geom, seed=79)
+    x, x1, _, _ = synth.synth_batch(geom, B=512, T=500, L=40, seed=3, ragged=False)
+    monkeypatch.setenv("MDD_LSTM", "step")
+    ref = _hip().HipModel(geom, sd, precision="f32").forward(_cuda(x), _cuda(x1), sync_errors=True).cpu().numpy()
+    monkeypatch.delenv("MDD_LSTM")
+    m = _hip().HipModel(geom, sd, precision="f32")
+    got = m.forward(_cuda(x), _cuda(x1), sync_errors=True).cpu().numpy()
+    np.testing.assert_array_equal(got, ref)
+    xb = x.copy()
+    xb[37, 100, 5] = np.nan
+    xb[37, 300, 7] = np.inf
+    bad = m.forward(_cuda(xb), _cuda(x1), sync_errors=True).cpu().numpy()
+    keep = [b for b in range(512) if b != 37]
+    np.testing.assert_array_equal(bad[:, keep], ref[:, keep])
+
+
+def test_gate_functions_accuracy():
+    """The short sigmoid / tanh of the reference-width recurrences (hardware exp2 / rcp + one Newton step; odd polynomial below
+    |v| = 1/4) against float64 on a dense sweep and on the special values: they stay at fp32 working accuracy -- the bound asserted
+    is 2 ulp of the result for sigmoid on [0, 8], 1e-7 absolute everywhere, and 4 ulp for tanh (measured values printed), where ATen's
+    Sleef kernels give ~1 ulp -- and hold their limits at the ends of the range."""
+    import ctypes as C
+    from ctc_attention_mispronunciation_amd import _lib
+    L = _lib.lib()
+    L.mdd_diag_gates.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+    rng = np.random.default_rng(5)
+    x = np.concatenate([rng.uniform(-20, 20, 400000), rng.uniform(-1, 1, 400000), rng.uniform(-0.3, 0.3, 200000),
+                        rng.standard_normal(200000) * 1e-3, np.linspace(0.2499, 0.2501, 2001),
+                        [0.0, -0.0, 0.25, -0.25, 1e-30, -1e-30, 88.0, -88.0, 100.0, -100.0, 1e4, -1e4, 3e38, -3e38, np.inf, -np.inf]]).astype(np.float32)
+    xd = torch.from_numpy(x).cuda()
+    sg, th = torch.empty_like(xd), torch.empty_like(xd)
+    assert L.mdd_diag_gates(xd.data_ptr(), sg.data_ptr(), th.data_ptr(), x.size, None) == 0, L.mdd_last_error().decode()
+    torch.cuda.synchronize()
+    sg, th = sg.cpu().numpy(), th.cpu().numpy()
+    x64 = x.astype(np.float64)
+    with np.errstate(over="ignore"):
+        sref, tref = 1.0 / (1.0 + np.exp(-x64)), np.tanh(x64)
+    assert np.isfinite(sg).all() and np.isfinite(th).all()
+    big = np.abs(x64) >= 1e-20
+    ulp_s = np.abs(sg - sref) / np.spacing(np.maximum(sref, 1e-30).astype(np.float32))
+    ulp_t = np.abs(th - tref)[big] / np.spacing(np.abs(tref[big]).astype(np.float32))
+    pos, neg = (x64 >= 0) & (x64 <= 8.0), (x64 < 0) & (x64 >= -8.0)
+    # sigmoid's argument product v * log2(e) is rounded once, so for v < 0 the RELATIVE error of the (small) result grows with |v|
+    # (~0.7 |v| ulp); what the cell update consumes is the absolute value, bounded below over the whole range
+    print("gate functions: sigmoid max %.2f ulp (mean %.3f) on [0, 8], %.2f ulp (mean %.3f) on [-8, 0), max |err| %.2e overall; tanh max %.2f ulp (mean %.3f), max |err| %.2e"
+          % (ulp_s[pos].max(), ulp_s[pos].mean(), ulp_s[neg].max(), ulp_s[neg].mean(), np.abs(sg - sref).max(), ulp_t.max(), ulp_t.mean(), np.abs(th - tref).max()))
+    assert ulp_s[pos].max() <= 2.0 and ulp_s[neg].max() <= 10.0 and ulp_t.max() <= 4.0
+    assert (np.abs(sg - sref) <= 1e-7).all() and (np.abs(th - tref) <= 1.2e-7).all()
+    assert (th[~big] == x[~big]).all()                            # tanh(v) = v to the last bit for tiny v, signed zeros kept
+    assert sg[x == np.inf][0] == 1.0 and sg[x == -np.inf][0] == 0.0 and th[x == np.inf][0] == 1.0 and th[x == -np.inf][0] == -1.0
+    nan = torch.full((4,), float("nan")).cuda()
+    s2, t2 = torch.empty_like(nan), torch.empty_like(nan)
+    assert L.mdd_diag_gates(nan.data_ptr(), s2.data_ptr(), t2.data_ptr(), 4, None) == 0
+    assert torch.isnan(s2).all() and torch.isnan(t2).all()
+
+
 @pytest.mark.parametrize("B", [512, 700])
 def test_persistent_lstm_stale_panel_redo_path(B, monkeypatch):
     """The BiLSTM uses a panel requested ahead without checking it first and redoes the tile's products when the tags
