@@ -14,13 +14,17 @@ reference masks nothing, so an utterance's result depends on its batch's padded 
 DIFFERENT padded lengths in one launch sequence with per-row (T_g, L_g), bit-identical to running each batch alone.  What real
 (ragged) data gets is reported in the same JSON line under `variants` (same run, rank 0, N=1): `ragged` (len ~ U[0.5,1] x 10 s,
 every batch padded to its own maximum, 8 such batches per fused pass, frames counted UNPADDED), `ragged_fuse1` / `fuse1` (a lone
-B=64 batch per pass: the latency-bound case), `f32_mode` (exact-fp32 MFMA arithmetic, MDD_PRECISION=f32), `greedy32_h256`
-(configs[1]) and `train32_f32` / `train32_bf16x3` (configs[4]'s per-GPU shard: a full training step in exact fp32 and in the flagged
-split-bf16 variant; `--workload train32 [--train-precision bf16x3]` prints that line on its own, with the stage split).
+B=64 batch per pass: the latency-bound case), `bf16x3_mode` (the flagged split-bf16 arithmetic, narrower than the reference's:
+MDD_PRECISION=bf16x3), `greedy32_h256` (configs[1]) and `train32_f32` / `train32_bf16x3` (configs[4]'s per-GPU shard: a full training
+step in exact fp32 and in the flagged split-bf16 variant; `--workload train32 [--train-precision bf16x3]` prints that line on its
+own, with the stage split).  The headline itself is REFERENCE-WIDTH arithmetic: every contraction an exact fp32 MFMA, as the
+reference's ATen fp32 ops (AA/models/model_ctc.py:27-29,59-66,149-158).
 
 N>1 (launched by torch.distributed.run, one rank per GPU): utterance batches shard across ranks (weak
 scaling: every rank decodes its own 64-utterance batch) and the posteriors of all shards are all-gathered
-over RCCL/xGMI each step, as BASELINE.json's north_star describes.
+over RCCL/xGMI each step on a stream of their own, behind the next pass's forward (`--gather posteriors`, what BASELINE.json's north_star
+names: 2.9 MB per rank and batch, 23 MB per rank and 8-batch pass), or -- the default, since nothing downstream of the decode
+consumes the other ranks' posteriors -- the decoded ids (`--gather ids`: [B, T'] int32 + lengths, 0.5 MB per rank and pass).
 
 Prints ONE JSON line on rank 0 (see the driver contract in the task statement) including `roofline`
 for the dominant kernel and a `cpu_baseline` measured in the same run on the host cores.
@@ -40,7 +44,7 @@ import torch  # noqa: E402
 PEAK_F32_MATRIX_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_* dense peak
 PEAK_BF16_MATRIX_TFLOPS = 2500.0 # dense bf16 MFMA peak (not the 2:1-sparsity figure)
 PEAK_HBM_GBS = 8000.0
-PMC_FILE = os.path.join(ROOT, "profiles", "round2_pmc_traffic.json")
+PMC_FILE = os.path.join(ROOT, "profiles", "round3_pmc_traffic.json")
 T_RAW, D_RAW, L_CANON, BEAM_W, N_CLASS = 1000, 81, 40, 10, 45
 
 
@@ -58,7 +62,9 @@ def parse():
     ap.add_argument("--precision", default=None, choices=[None, "f32", "bf16x3"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-variants", action="store_true", help="skip the fuse1 / ragged / f32_mode / greedy32_h256 lines")
-    ap.add_argument("--no-gather", action="store_true", help="skip the posterior all-gather at N>1")
+    ap.add_argument("--gather", default="ids", choices=["ids", "posteriors", "none"],
+                    help="what the ranks exchange per pass at N>1 (own stream, overlapped with the next forward): decoded ids (default) or the posteriors")
+    ap.add_argument("--no-gather", action="store_true", help="same as --gather none")
     ap.add_argument("--decoder", default=None, choices=[None, "beam", "greedy", "none"], help="diagnostic override of the decode stage")
     ap.add_argument("--no-roofline", action="store_true", help="skip the stage-replay pass (for clean traces)")
     return ap.parse_args()
@@ -113,7 +119,7 @@ class DecodeJob(object):
     """One configuration of the hot path: model, resident inputs, two-stream pipeline (forward of pass i+1 on s_fwd
     beside the beam search + D2H of pass i on s_dec; the host aligns pass i meanwhile)."""
 
-    def __init__(self, ctx, args, hidden, joint, fuse, ragged, precision, decoder_kind=None, gather=True):
+    def __init__(self, ctx, args, hidden, joint, fuse, ragged, precision, decoder_kind=None, gather="ids"):
         from ctc_attention_mispronunciation_amd import synth, dist as mdist
         from ctc_attention_mispronunciation_amd.hip_model import HipModel
         from ctc_attention_mispronunciation_amd.utils.ctcDecoder import GreedyDecoder, BeamDecoder
@@ -130,11 +136,19 @@ class DecodeJob(object):
         self.decoder_kind = kind
         self.decoder = (BeamDecoder(self.i2c, beam_width=BEAM_W, blank_index=0, space_idx=-1, lm_path=arpa, lm_alpha=0.0)
                         if kind == "beam" else GreedyDecoder(self.i2c, space_idx=-1, blank_index=0))
-        self.gather = gather and ctx.dist is not None
-        self.s_fwd, self.s_dec = torch.cuda.Stream(), torch.cuda.Stream()
+        self.gather = gather if (ctx.dist is not None and gather != "none") else None
+        if self.gather == "ids" and kind == "none":
+            self.gather = None
+        self.s_fwd, self.s_dec, self.s_comm = torch.cuda.Stream(), torch.cuda.Stream(), torch.cuda.Stream()
+        self.ev_tf0 = [torch.cuda.Event(enable_timing=True) for _ in range(4)]   # device timestamps around each forward (by pass number & 3)
+        self.ev_tf1 = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
         self.ev_fwd = [torch.cuda.Event() for _ in range(2)]
         self.ev_dec = [torch.cuda.Event() for _ in range(2)]
         self.ev_free = [torch.cuda.Event() for _ in range(2)]
+        self.ev_c0 = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        self.ev_comm = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        self.comm_pending = [False, False]
+        self.gather_ms, self.fwd_gap_ms, self.last_slot = [], [], None
         self.count = 0
         self.aligned = []
         self.frames_done = 0
@@ -210,7 +224,10 @@ class DecodeJob(object):
     def _alloc_out(self, bf):
         w = self.ctx.world
         bf.logp = [torch.empty((bf.Tp, bf.b, N_CLASS), device="cuda") for _ in range(2)]
-        bf.gathered = [torch.empty((w, bf.Tp, bf.b, N_CLASS), device="cuda") for _ in range(2)] if self.gather else None
+        bf.gathered = [torch.empty((w, bf.Tp, bf.b, N_CLASS), device="cuda") for _ in range(2)] if self.gather == "posteriors" else None
+        bf.g_ids = [torch.empty((w, bf.b, bf.Tp), dtype=torch.int32, device="cuda") for _ in range(2)] if self.gather == "ids" else None
+        bf.g_n = [torch.empty((w, bf.b), dtype=torch.int32, device="cuda") for _ in range(2)] if self.gather == "ids" else None
+        bf.dev_out = [None, None]
         bf.h_ids = [torch.empty((bf.b, bf.Tp), dtype=torch.int32).pin_memory() for _ in range(2)]
         bf.h_n = [torch.empty((bf.b,), dtype=torch.int32).pin_memory() for _ in range(2)]
 
@@ -230,10 +247,13 @@ class DecodeJob(object):
     def enqueue(self, item):
         """item: number of fused batches (uniform set) or the index of a ragged batch."""
         bf = self._rag_bufs(item) if self.ragged else self._bufs(item)
-        k = self.count & 1
+        k, q = self.count & 1, self.count & 3
         self.count += 1
         with torch.cuda.stream(self.s_fwd):
             self.s_fwd.wait_event(self.ev_free[k])          # slot k's buffers no longer read by the decoder two passes ago
+            if self.comm_pending[k]:
+                self.s_fwd.wait_event(self.ev_comm[k])      # ... nor by that pass's result exchange
+            self.ev_tf0[q].record(self.s_fwd)
             if self.ragged:
                 if self.fuse > 1:
                     self.model.forward_fused(bf.x, bf.x1, bf.bframes, bf.bcanon, out=bf.logp[k])
@@ -241,23 +261,51 @@ class DecodeJob(object):
                     self.model.forward(bf.x, bf.x1, out=bf.logp[k])
             else:
                 self.model.forward_raw(bf.raw, bf.x1, out=bf.logp[k])    # stack/skip folded into the front-end's tile load
-            if bf.gathered is not None:
-                self.mdist.gather_posteriors(bf.logp[k], out=bf.gathered[k])
             self.ev_fwd[k].record(self.s_fwd)
+            self.ev_tf1[q].record(self.s_fwd)
         with torch.cuda.stream(self.s_dec):
             self.s_dec.wait_event(self.ev_fwd[k])
             if self.decoder_kind != "none":
                 out = self.decoder.decode_ids(bf.logp[k], bf.lens)
+                bf.dev_out[k] = out                          # kept until the slot is reused: the exchange reads them on another stream
                 bf.h_ids[k].copy_(out[0], non_blocking=True)
                 bf.h_n[k].copy_(out[1], non_blocking=True)
             self.ev_free[k].record(self.s_dec)
             self.ev_dec[k].record(self.s_dec)
-        return (bf, k)
+        return (bf, k, q)
+
+    def exchange(self, pend):
+        """N>1: the result exchange of a pass, on its own stream.  It is issued AFTER the next pass's forward has been enqueued
+        (host order) and depends only on its own pass's events (device order), so it runs beside that forward instead of in front of
+        it; the forward that reuses the slot two passes later waits for it."""
+        if self.gather is None:
+            return
+        bf, k, _ = pend
+        delay = float(os.environ.get("MDD_BENCH_GATHER_DELAY_MS", "0"))   # test aid: a spinning kernel in front of the collective makes
+        with torch.cuda.stream(self.s_comm):                               # the exchange long enough to show up in the stream timestamps
+            if self.gather == "posteriors":
+                self.s_comm.wait_event(self.ev_fwd[k])
+                self.ev_c0[k].record(self.s_comm)
+                if delay > 0:
+                    torch.cuda._sleep(int(delay * 1.5e6))
+                self.mdist.gather_posteriors(bf.logp[k], out=bf.gathered[k])
+            else:
+                self.s_comm.wait_event(self.ev_dec[k])
+                self.ev_c0[k].record(self.s_comm)
+                self.mdist.gather_decoded(bf.dev_out[k][0], bf.dev_out[k][1], out=(bf.g_ids[k], bf.g_n[k]))
+            self.ev_comm[k].record(self.s_comm)
+        self.comm_pending[k] = True
 
     def finish(self, pend):
         from ctc_attention_mispronunciation_amd.utils.ctcDecoder import align_ids_batch
-        bf, k = pend
+        bf, k, q = pend
         self.ev_dec[k].synchronize()
+        if self.comm_pending[k]:
+            self.ev_comm[k].synchronize()
+            self.gather_ms.append(self.ev_c0[k].elapsed_time(self.ev_comm[k]))
+        if self.gather is not None and self.last_slot == ((q - 1) & 3):   # idle time of the forward stream between two consecutive passes
+            self.fwd_gap_ms.append(self.ev_tf1[self.last_slot].elapsed_time(self.ev_tf0[q]))
+        self.last_slot = q
         tot = 0
         if self.decoder_kind != "none":
             d = align_ids_batch(bf.h_ids[k].numpy(), bf.h_n[k].numpy(), bf.canon, bf.canon_len)[0]   # one native call per pass
@@ -274,9 +322,14 @@ class DecodeJob(object):
     def run(self, items):
         pending = []
         for it in items:
-            pending.append(self.enqueue(it))
+            cur = self.enqueue(it)
+            if pending:
+                self.exchange(pending[-1])                       # the previous pass's results, behind this pass's forward
+            pending.append(cur)
             if len(pending) > 1:                                 # keep at most one finished-but-unaligned pass
                 self.finish(pending.pop(0))
+        if pending:
+            self.exchange(pending[-1])
         for p in pending:
             self.finish(p)
 
@@ -300,6 +353,7 @@ class DecodeJob(object):
         self.ctx.barrier()
         self.aligned.clear()
         self.frames_done = 0
+        self.gather_ms, self.fwd_gap_ms, self.last_slot = [], [], None
         t0 = time.perf_counter()
         self.run(timed)
         self.ctx.barrier()
@@ -314,18 +368,24 @@ class DecodeJob(object):
         return dt, self.frames_done
 
     def verify_gather(self):
-        """N>1: every rank's slice of the last gathered buffer equals its own posteriors, and the slices of the other ranks
+        """N>1: every rank's slice of the last exchanged buffers equals its own results, and the slices of the other ranks
         differ from it (they decode different shards).  Returns True/False agreed over all ranks (None at N=1)."""
-        if not self.gather:
+        if self.gather is None:
             return None
         ok = True
         for bf in ([r["bf"] for r in self.rag if "bf" in r] if self.ragged else list(self.sets.values())):
             for k in range(2):
                 if self.count < 2 and k >= self.count:
                     continue                                  # slot never used
-                own = bf.gathered[k][self.ctx.rank]
-                ok = ok and bool(torch.equal(own, bf.logp[k]))
-                ok = ok and all(not torch.equal(bf.gathered[k][r], own) for r in range(self.ctx.world) if r != self.ctx.rank)
+                if self.gather == "posteriors":
+                    own, mine = bf.gathered[k][self.ctx.rank], bf.logp[k]
+                    others = [bf.gathered[k][r] for r in range(self.ctx.world) if r != self.ctx.rank]
+                else:
+                    own, mine = bf.g_ids[k][self.ctx.rank], bf.dev_out[k][0]
+                    ok = ok and bool(torch.equal(bf.g_n[k][self.ctx.rank], bf.dev_out[k][1]))
+                    others = [bf.g_ids[k][r] for r in range(self.ctx.world) if r != self.ctx.rank]
+                ok = ok and bool(torch.equal(own, mine))
+                ok = ok and all(not torch.equal(o, own) for o in others)
         t = torch.tensor([1.0 if ok else 0.0], device="cpu" if self.ctx.dist.get_backend() == "gloo" else "cuda")
         self.ctx.dist.all_reduce(t, op=self.ctx.dist.ReduceOp.MIN)
         return bool(t.item() > 0.5)
@@ -349,7 +409,9 @@ class DecodeJob(object):
 
         def kernel_of(name):   # which hand-written kernel a stage runs (depends on the precision mode in use)
             if name.startswith("lstm"):
-                return "lstm_layer_granule_kernel" if x3 else "lstm_step_packed_kernel"
+                if os.environ.get("MDD_LSTM") == "step" or B > 1024:
+                    return "lstm_step_x3_kernel" if x3 else "lstm_step_packed_kernel"
+                return "lstm_layer_granule_kernel" if x3 else "lstm_layer_f32_kernel"
             if name.startswith("gemm"):
                 if not x3:
                     return "gemm_nt_f32_kernel"
@@ -390,8 +452,11 @@ class DecodeJob(object):
 DTYPE_X3 = ("f32 results from split-bf16 arithmetic: every contraction of the model -- conv0/conv1, the BiLSTM input projections AND the "
             "recurrent W_hh.h products, text projection, score and attention-score GEMMs -- runs as bf16 hi/lo x3 on the bf16 MFMA pipes "
             "with fp32 accumulate (operands ~16 significant bits, the recurrent state h is re-split to hi+lo every step); cell state, gates, "
-            "softmax and the classifier tail are fp32.  Log-probs within 1e-4 of the fp32 reference at T'=250 (tests/golden/g9_chain); "
-            "exact-fp32 MFMA mode reported under variants.f32_mode")
+            "softmax and the classifier tail are fp32.  Log-probs within 1e-4 of the fp32 reference at T'=250 (tests/golden/g9_chain).  "
+            "NARROWER than the reference's fp32 arithmetic: a flagged variant, not the headline")
+DTYPE_F32 = ("f32 -- reference width: every contraction of the model (conv0/conv1, BiLSTM input projections, the recurrent W_hh.h products, "
+             "text projection, score, attention scores, classifier) is an exact fp32 MFMA (v_mfma_f32_32x32x2_f32 / 16x16x4_f32, fp32 "
+             "accumulate), gates / softmax fp32, beam scores f64 -- the arithmetic of the reference's ATen fp32 ops")
 
 
 def variant(ctx, args, name, **kw):
@@ -549,7 +614,7 @@ def main():
 
     joint = args.workload == "joint64"
     job = DecodeJob(ctx, args, hidden=args.hidden, joint=joint, fuse=args.fuse, ragged=args.ragged, precision=args.precision,
-                    decoder_kind=args.decoder, gather=not args.no_gather)
+                    decoder_kind=args.decoder, gather="none" if args.no_gather else args.gather)
     dt, frames = job.timed(args.steps, args.warmup)
     G = max(1, min(args.fuse, args.steps))
     if ctx.dist is not None:
@@ -562,6 +627,13 @@ def main():
     precision = job.model.precision
     checksum = int(sum(job.aligned))
     gather_ok = job.verify_gather()
+    gather_kind = job.gather
+    gather_timing = None
+    if job.gather is not None and job.gather_ms:
+        gather_timing = {"what": job.gather, "gather_ms_median": round(float(np.median(job.gather_ms)), 4),
+                         "forward_stream_gap_ms_median": round(float(np.median(job.fwd_gap_ms)), 4) if job.fwd_gap_ms else None,
+                         "note": "gap = idle time of the forward stream between consecutive passes (device timestamps); the exchange of pass i runs on "
+                                 "its own stream beside the forward of pass i+1"}
 
     roof = job.roofline(G) if (rank == 0 and not args.no_roofline) else None
 
@@ -597,8 +669,9 @@ def main():
             "fuse1": variant(ctx, args, "fuse1", hidden=args.hidden, joint=True, fuse=1, ragged=False, precision=args.precision, steps=32, warmup=8),
             "ragged": variant(ctx, args, "ragged", hidden=args.hidden, joint=True, fuse=args.fuse, ragged=True, precision=args.precision, steps=64, warmup=16),
             "ragged_fuse1": variant(ctx, args, "ragged_fuse1", hidden=args.hidden, joint=True, fuse=1, ragged=True, precision=args.precision, steps=32, warmup=8),
-            "f32_mode": variant(ctx, args, "f32_mode", hidden=args.hidden, joint=True, fuse=args.fuse, ragged=False, precision="f32", steps=16, warmup=8,
-                                roofline=True),
+            ("f32_mode" if precision == "bf16x3" else "bf16x3_mode"):
+                variant(ctx, args, "other_mode", hidden=args.hidden, joint=True, fuse=args.fuse, ragged=False,
+                        precision="f32" if precision == "bf16x3" else "bf16x3", steps=64, warmup=16, roofline=True),
             "greedy32_h256": variant(ctx, args, "greedy32_h256", hidden=256, joint=False, fuse=args.fuse, ragged=False, precision=args.precision,
                                      steps=64, warmup=16),
             "greedy32_h256_fuse1": variant(ctx, args, "greedy32_h256_fuse1", hidden=256, joint=False, fuse=1, ragged=False, precision=args.precision,
@@ -619,7 +692,7 @@ def main():
             "value": round(value, 1), "unit": "phoneme-frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
-            "dtype": DTYPE_X3 if precision == "bf16x3" else "f32 (exact fp32 MFMA everywhere)",
+            "dtype": DTYPE_X3 if precision == "bf16x3" else DTYPE_F32,
             "data": "synthetic",
             "config": {"workload": ("joint CTC-attn decode: stack/skip + forward + beam(10) + align, B=64 x 10 s x 81-dim log-mel"
                                     if joint else "CTC-only greedy decode: stack/skip + forward + greedy + align, B=32 x 10 s"),
@@ -629,16 +702,18 @@ def main():
                        "t_raw": T_RAW, "posterior_frames": T_RAW // 4,
                        "hidden": args.hidden, "layers": 4, "num_class": N_CLASS, "canonical_len": L_CANON,
                        "decoder": decoder_kind, "beam": BEAM_W if decoder_kind == "beam" else 0, "lm_alpha": 0.0,
-                       "parallelism": "utterance-batch shards x%d%s" % (world, ", all-gather posteriors" if world > 1 and not args.no_gather else ""),
+                       "parallelism": "utterance-batch shards x%d%s" % (world, (", all-gather of %s on its own stream" % gather_kind) if gather_kind else ""),
                        "posteriors": "random-weight model output (flat: every frame live, beam worst case)"},
             "roofline": roof, "cpu_baseline": cpu, "variants": variants,
             "edit_distance_checksum": checksum,
         }
         if gather_ok is not None:
             line["gather_verified"] = gather_ok
+            line["gather_timing"] = gather_timing
         if variants:
-            for k in ("fuse1", "ragged", "f32_mode", "greedy32_h256", "train32_f32", "train32_bf16x3"):
-                line[k] = variants[k]["value"]
+            for k in ("fuse1", "ragged", "f32_mode", "bf16x3_mode", "greedy32_h256", "train32_f32", "train32_bf16x3"):
+                if k in variants:
+                    line[k] = variants[k]["value"]
         print(json.dumps(line))
     if ctx.dist is not None:
         ctx.dist.destroy_process_group()

@@ -52,7 +52,7 @@ struct mdd_model {
     mdd_config cfg;
     int device = 0;
     bool finalized = false, taps = false, use_graph = true;
-    int precision = 1;   // 0: exact fp32 MFMA everywhere, 1: split-bf16 x3 for the time-batched GEMMs (when the geometry allows)
+    int precision = 0;   // 0 (default): reference width, exact fp32 MFMA everywhere; 1: split-bf16 x3 for every contraction (when the geometry allows; flagged variant)
     std::map<std::string, std::vector<float>> host;  // state_dict entries as loaded
     // device weights
     float *w_conv0 = nullptr, *sc0 = nullptr, *sh0 = nullptr;
@@ -375,6 +375,7 @@ extern "C" int mdd_create(const mdd_config *cfg, int device, mdd_model **out) {
     m->device = device;
     const char *pr = getenv("MDD_PRECISION");
     if (pr && (!strcmp(pr, "f32") || !strcmp(pr, "0"))) m->precision = 0;
+    if (pr && (!strcmp(pr, "bf16x3") || !strcmp(pr, "1"))) m->precision = 1;
     const char *lx = getenv("MDD_LSTM");
     m->lstm_x3 = lx && !strcmp(lx, "x3");
     if (lx && !strcmp(lx, "step")) m->lstm_persist = false;

@@ -155,25 +155,21 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_f32_kernel(PersistArgs a) {
     const bool two_out = a.out_raw && a.out && a.out_raw != a.out;
     float *const out_main = a.out ? a.out : a.out_raw;             // what the Os tile goes to
     auto tile_rows = [&](int bt) { const int nv = min(a.BGr, B - g * a.BGr) - bt * 16; return nv < 0 ? 0 : (nv > 16 ? 16 : nv); };
-    auto store_out = [&](int bt, int tt) -> int {
+    auto store_out = [&](int bt, int tt) {
         const int nr = tile_rows(bt);
-        if (nr == 0) return 0;
+        if (nr == 0) return;
         const int r = min(orow, nr - 1);
         const unsigned el = lane < PWR ? (unsigned)((g * a.BGr + bt * 16 + r) * 2 * H + d * H + member * UW + ocol) : 0x3fffffffu;
-        int issued = 0;
         if (out_main) {
             const u32x4 v = *reinterpret_cast<const u32x4 *>(Os + r * UW + ocol);
             const __amdgpu_buffer_rsrc_t rs_ = __builtin_amdgcn_make_buffer_rsrc(out_main + (size_t)tt * slab, 0, (int)(slab * 4), 0x00020000);
             __builtin_amdgcn_raw_buffer_store_b128(v, rs_, el * 4u, 0, 0);
-            issued++;
         }
         if (two_out) {
             const u32x4 v = *reinterpret_cast<const u32x4 *>(Or + r * UW + ocol);
             const __amdgpu_buffer_rsrc_t rs_ = __builtin_amdgcn_make_buffer_rsrc(a.out_raw + (size_t)tt * slab, 0, (int)(slab * 4), 0x00020000);
             __builtin_amdgcn_raw_buffer_store_b128(v, rs_, el * 4u, 0, 0);
-            issued++;
         }
-        return issued;
     };
 
     // Step 0 has no state to multiply: its phases run the product loop on an all-zero panel (exact zeros out), which keeps the loop
@@ -260,30 +256,32 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_f32_kernel(PersistArgs a) {
             }
             FSTAMP(3);
             // ---- publish h_s (write-through, no drain, no signal) and the layer outputs; a wave reads back only what it wrote itself
-            int after = 0;                                          // memory instructions issued after the (re-)request of the next panel
             {
                 const u32x4 pv = *reinterpret_cast<const u32x4 *>(Og + qp * 4);
                 if (s + 1 < T) {
                     const __amdgpu_buffer_rsrc_t drs = __builtin_amdgcn_make_buffer_rsrc(hxg + (size_t)((s & 1) * 32 + team) * pgran + bt * tgran, 0, (int)(tgran * 8), 0x00020000);
                     __builtin_amdgcn_raw_buffer_store_b128(pv, drs, offp, 0, 16 /* sc1 */);
-                    after++;
                 }
                 if (next_needs && !in_loop) {
-                    // one tile (nothing to overlap), or the first step (no product loop to request from): the panel is requested
+                    // one tile (nothing to overlap), or the first step (no earlier phase to request from): the panel is requested
                     // here and polled below; the outputs leave behind the request.  With one tile it is the panel this very
                     // publish goes into: a request sent before the publish is acknowledged only finds stale tags
                     if (NBT == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     request_sweep(nbt, ns - 1, pb ^ 1);
-                    stale = true; after = 0;
+                    stale = true;
                 }
-                after += store_out(bt, t);
+                store_out(bt, t);
             }
             FSTAMP(4);
-            // ---- the next phase's panel: every wave answers for the pieces it fetched itself
+            // ---- the next phase's panel: every wave answers for the pieces it fetched itself.  Always a full vmcnt(0) in front of
+            // the check: a counted wait (the split-bf16 kernel's vmcnt(K) past the younger stores) let the check read chunks
+            // whose first words had landed and whose last had not -- run-to-run differences with one tile per team, found by
+            // test_fused_batches_of_different_lengths_equal_their_own_runs -- and the store acknowledgements it would skip
+            // (~1 us) arrive before a panel requested right after the publish can be fresh (~2 us) anyway.
             if (stale) {
                 long long t0 = 0;
                 int polls = 0;
-                wait_vmcnt(after);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 while (pieces_stale(pb ^ 1, ns - 1)) {
                     if ((++polls & 63) == 0) {
                         int ab = 0;

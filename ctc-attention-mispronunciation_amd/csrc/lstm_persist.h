@@ -15,14 +15,19 @@ __device__ __forceinline__ float sigmoid_f(float v) { return 1.f / (1.f + expf(-
 // the two bit-identical).  An fp32 MFMA runs on the SIMD's fp32 lanes: unlike next to a bf16 MFMA, every vector instruction of the
 // cell update is time the matrix products do not get, so the libm forms (~40 instructions per call) are replaced by short ones built
 // on the hardware exp2 / rcp (1 ulp each) that stay at fp32 working accuracy in the sense the cell update needs: absolute error
-// <= 9e-8 (sigmoid) / 1.2e-7 (tanh) over the whole range; relative: sigmoid <= 1.6 ulp for v >= 0 and ~0.7 |v| ulp of its (small)
+// <= 9e-8 (sigmoid) / 1.3e-7 (tanh) over the whole range; relative: sigmoid <= 1.6 ulp for v >= 0 and ~0.7 |v| ulp of its (small)
 // result for v < 0 (the argument product is rounded once), tanh <= 3.9 ulp
 // (measured against fp64 in tests/test_gpu_parity.py::test_gate_functions_accuracy).
 //   sigmoid(v) = 1 / (1 + 2^(-v log2 e)), the reciprocal refined by one Newton step; the exponent is capped so that 1 + e stays finite
 //   tanh(v)    = sign(v) (1 - e) / (1 + e), e = 2^(-2 |v| log2 e) for |v| >= 1/4; the odd Taylor polynomial up to v^9 below that
 //                (1 - e cancels there; the next term, 1382/155925 v^10, is < 1e-8 relative at 1/4)
+#ifdef MDD_GATES_LIBM   // experiment switch: the libm forms (accuracy yardstick for the short ones)
+__device__ __forceinline__ float gate_sigmoid(float v) { return 1.f / (1.f + expf(-v)); }
+__device__ __forceinline__ float gate_tanh(float v) { return tanhf(v); }
+#else
 __device__ __forceinline__ float gate_sigmoid(float v) {
-    const float e = __builtin_amdgcn_exp2f(fminf(v * -1.44269504088896340736f, 126.f));
+    const float a = v * -1.44269504088896340736f;
+    const float e = __builtin_amdgcn_exp2f(a > 126.f ? 126.f : a);      // (a select, not fminf: a NaN must stay a NaN)
     const float d = 1.f + e, r = __builtin_amdgcn_rcpf(d);
     return __builtin_fmaf(r, __builtin_fmaf(-d, r, 1.f), r);
 }
@@ -37,6 +42,7 @@ __device__ __forceinline__ float gate_tanh(float v) {
     const float small = __builtin_fmaf(a, p * v2, a);
     return __builtin_copysignf(a < 0.25f ? small : big, v);
 }
+#endif
 
 
 struct PersistArgs {

@@ -37,7 +37,7 @@ def _all_gather_rows(out, src):
 def gather_posteriors(logp, out=None):
     """All-gather equal-shape posteriors [T', B, C] of every rank -> [world, T', B, C] (one collective)."""
     _, w = world()
-    if w == 1:
+    if w == 1 and out is None:
         return logp.unsqueeze(0)
     if out is None:
         out = torch.empty((w,) + tuple(logp.shape), dtype=logp.dtype, device=logp.device)
@@ -45,13 +45,17 @@ def gather_posteriors(logp, out=None):
     return out
 
 
-def gather_decoded(ids, nids):
-    """All-gather decoded ids [B, T'] int32 and their lengths [B] -> lists of per-rank tensors."""
+def gather_decoded(ids, nids, out=None):
+    """All-gather decoded ids [B, T'] int32 and their lengths [B] -> lists of per-rank tensors (views of `out` =
+    ([world, B, T'], [world, B]) when given)."""
     _, w = world()
-    if w == 1:
+    if w == 1 and out is None:
         return [ids], [nids]
-    all_ids = torch.empty((w,) + tuple(ids.shape), dtype=ids.dtype, device=ids.device)
-    all_n = torch.empty((w,) + tuple(nids.shape), dtype=nids.dtype, device=nids.device)
+    if out is None:
+        all_ids = torch.empty((w,) + tuple(ids.shape), dtype=ids.dtype, device=ids.device)
+        all_n = torch.empty((w,) + tuple(nids.shape), dtype=nids.dtype, device=nids.device)
+    else:
+        all_ids, all_n = out
     _all_gather_rows(all_ids.view((-1,) + tuple(ids.shape[1:])), ids)
     _all_gather_rows(all_n.view(-1), nids)
     return list(all_ids.unbind(0)), list(all_n.unbind(0))

@@ -54,8 +54,30 @@ def allreduce_gradients(model, bucket_bytes=64 << 20):
 
 
 def run_epoch(epoch_id, model, data_iter, loss_fn, device, optimizer=None, print_every=20, is_training=True):
+    """AA/steps/train_ctc.py:28-105, same arguments, prints and return value.  The reference pulls the loss (``loss.item()``) and the
+    frame argmax (``torch.max`` + ``compute_wer`` on numpy copies) to the host on EVERY step; at 14-33 ms per HIP step those two
+    synchronisations are no longer free, so the bookkeeping stays on the device: the loss is accumulated in a float64 device
+    scalar (the same sum, in the same order, as the reference's Python float), the greedy prediction of ``compute_wer``
+    (argmax, drop repeats, drop blanks: model_ctc.py:227-244) is mdd_greedy's output, and both come to the host once per print
+    interval, where the edit distances of all pending utterances are one native call (mdd_align_batch)."""
+    import numpy as np
+    from ..utils.ctcDecoder import GreedyDecoder, align_ids_batch
     model.train() if is_training else model.eval()
     total_loss, total_tokens, total_errs, i = 0, 0, 0, -1
+    greedy = GreedyDecoder({}, space_idx=-1, blank_index=0)
+    loss_acc, pending = None, []
+
+    def flush():
+        nonlocal total_loss, total_tokens, total_errs, loss_acc, pending
+        if loss_acc is not None:
+            total_loss = float(loss_acc.item())               # the one host synchronisation of the interval
+        for ids, n, tg, tl in pending:
+            ids, n, tg, tl = ids.cpu().numpy(), n.cpu().numpy(), tg.cpu().numpy().astype(np.int32), tl.cpu().numpy().astype(np.int32)
+            dist = align_ids_batch(tg, tl, ids, n)[0]
+            empty = dist < 0                                  # ed.eval with an empty side = the length of the other one
+            total_errs += int(dist[~empty].sum()) + int(np.maximum(tl, n)[empty].sum())
+            total_tokens += int(tl.sum())
+        pending = []
     for i, data in enumerate(data_iter):
         inputs, input_sizes, targets, target_sizes, trans, trans_sizes, utt_list = data
         inputs, input_sizes = inputs.to(device), input_sizes.to(device)
@@ -66,19 +88,26 @@ def run_epoch(epoch_id, model, data_iter, loss_fn, device, optimizer=None, print
             input_sizes = (input_sizes * out_len).long()
             loss = loss_fn(out, targets, input_sizes, target_sizes)
             loss = loss / batch_size
-        total_loss += loss.item()
-        _, index = torch.max(out.detach(), dim=-1)
-        batch_errs, batch_tokens = model.compute_wer(index.transpose(0, 1).cpu().numpy(), input_sizes.cpu().numpy(), targets.cpu().numpy(),
-                                                     target_sizes.cpu().numpy())
-        total_errs += batch_errs
-        total_tokens += batch_tokens
+        if out.is_cuda:
+            loss_acc = loss.detach().double() if loss_acc is None else loss_acc + loss.detach().double()
+            ids, n = greedy.decode_ids(out.detach(), input_sizes)
+            pending.append((ids, n, targets, target_sizes))
+        else:                                                 # (CPU inputs: the forward has copied the posteriors back already)
+            total_loss += loss.item()
+            _, index = torch.max(out.detach(), dim=-1)
+            batch_errs, batch_tokens = model.compute_wer(index.transpose(0, 1).cpu().numpy(), input_sizes.cpu().numpy(), targets.cpu().numpy(),
+                                                         target_sizes.cpu().numpy())
+            total_errs += batch_errs
+            total_tokens += batch_tokens
         if (i + 1) % print_every == 0 and is_training:
+            flush()
             print('Epoch = %d, step = %d, total_loss = %.4f, total_wer = %.4f' % (epoch_id, i + 1, total_loss / (i + 1), total_errs / total_tokens))
         if is_training:
             optimizer.zero_grad()
             loss.backward()
             allreduce_gradients(model)
             optimizer.step()
+    flush()
     average_loss = total_loss / (i + 1)
     print("Epoch %d %s done, total_loss: %.4f, total_wer: %.4f" % (epoch_id, "Train" if is_training else "Valid", average_loss, total_errs / total_tokens))
     return 1 - total_errs / total_tokens, average_loss

@@ -17,6 +17,7 @@ What is imported:
                              (function definitions only, extracted with ast because the
                              module has import-time argparse + absent deps) -> G7
   all of the above chained as AA/infer.py:294-342 does, at T'=250 -> G9 (g9_chain.*)
+  the same chain for each of the 20 words of egs/vocabulary/single, canonicals from AA/dict/phonetic_dict.py's CMU lookup -> G12
   torch.nn.CTCLoss(reduction='sum') as called at AA/steps/train_ctc.py:72,186 -> G5
 
 Usage:  python oracle/gen_golden.py            (writes tests/golden/*)
@@ -670,6 +671,72 @@ def gen_aug_goldens():
     print("G10 aug: %d items, %d enhancement runs, lexicon:" % (len(recs), len(enh)), [(r["word"], r["model"]) for r in lexrec[:4]], "...")
 
 
+# ----------------------------------------------------------------------------- G12 (BASELINE configs[0]: every word of egs/vocabulary/single)
+def gen_words_goldens():
+    """configs[0] over all 20 WAV / TXT pairs of egs/vocabulary/single (copied to tests/golden/vocabulary_single/ as data):
+    TXT -> the reference's CMU-dictionary lookup (AA/dict/phonetic_dict.py load_cmudict / cmu_dict, extracted with ast as in G10) ->
+    the stress post-processing of AA/infer.py:543-548 -> canonical ids; WAV -> OUR restatement of Kaldi's fbank + CMVN + stack/skip
+    (Kaldi itself is absent: feature parity unpinned) -> the REFERENCE model (seeded synthetic weights: the trained checkpoint is not
+    in the tree) -> the reference's chain (AA/infer.py:294-342: BeamDecoder(10) / GreedyDecoder, wer, align_canonical_decoded,
+    stastics, score).  Words the dictionary does not hold (the reference then asks g2p_en / espeak, absent offline) are recorded
+    without a chain."""
+    import shutil
+    import wave
+    sys.path.insert(0, ROOT)
+    from oracle import oracle as orc
+    sys.path.pop(0)
+    int2char = synth.phone_table_41()
+    c2i = {v: k for k, v in int2char.items()}
+    arpa = os.path.join(OUT, "lm_synth45.arpa")
+    helpers = load_infer_functions()
+    greedy = GreedyDecoder(int2char, space_idx=-1, blank_index=0)
+    beam = BeamDecoder(int2char, beam_width=10, blank_index=0, space_idx=-1, lm_path=arpa, lm_alpha=0.0)
+    src = open(os.path.join(AA, "dict", "phonetic_dict.py")).read()
+    cls = [n for n in ast.parse(src).body if isinstance(n, ast.ClassDef) and n.name == "Phonetic"][0]
+    meths = [n for n in cls.body if isinstance(n, ast.FunctionDef) and n.name in ("load_cmudict", "cmu_dict")]
+    stub = ast.ClassDef(name="RefLexicon", bases=[], keywords=[], body=meths, decorator_list=[])
+    ns = {"os": os, "__file__": os.path.join(AA, "dict", "phonetic_dict.py")}
+    exec(compile(ast.fix_missing_locations(ast.Module(body=[stub], type_ignores=[])), "phonetic_dict.py<lexicon>", "exec"), ns)
+    lex = ns["RefLexicon"]()
+    lex.cmudict_plain = {}
+    import string
+    vdir = "/root/reference/egs/vocabulary/single"
+    wdir = os.path.join(OUT, "vocabulary_single")
+    os.makedirs(wdir, exist_ok=True)
+    geom = synth.Geometry(**synth.REFERENCE)
+    sd = synth.synth_state_dict(geom, seed=11)
+    m = build_reference_model(geom, sd)
+    stats = orc.read_cmvn_stats(os.path.join(OUT, "global_fbank_cmvn.txt"))
+    arrays, meta = {}, []
+    for i in range(1, 21):
+        for ext in ("wav", "txt"):
+            shutil.copyfile(os.path.join(vdir, "%d.%s" % (i, ext)), os.path.join(wdir, "%d.%s" % (i, ext)))
+            os.chmod(os.path.join(wdir, "%d.%s" % (i, ext)), 0o644)
+        word = open(os.path.join(vdir, "%d.txt" % i)).read().strip()
+        w = wave.open(os.path.join(vdir, "%d.wav" % i))
+        assert w.getframerate() == 16000 and w.getnchannels() == 1 and w.getsampwidth() == 2
+        wav = np.frombuffer(w.readframes(w.getnframes()), dtype=np.int16).astype(np.float32)
+        cmu = lex.cmu_dict(word)
+        rec = dict(i=i, word=word, cmu=cmu, samples=int(wav.size))
+        if cmu:
+            parts_ = [p.rstrip(string.digits) if p not in ["ER0", "AH0"] else p for p in cmu.split(" ")]      # infer.py:545-547
+            canon = " ".join(p.lower() for p in parts_)
+            feats = orc.stack_skip(orc.apply_cmvn(orc.fbank(wav), stats))
+            x1 = np.array([[c2i[p] for p in canon.split()]], dtype=np.int64)
+            with torch.no_grad():
+                logp = m(torch.from_numpy(feats[None]), torch.from_numpy(x1)).numpy()
+            arrays["logp%d" % i] = logp
+            rec.update(canonical=canon, T=int(feats.shape[0]),
+                       records=chain_records(logp, np.ones(1, dtype=np.float32), x1, np.array([x1.shape[1]]), int2char, beam, greedy, helpers))
+            print("G12", i, word, "->", canon, "| beam:", rec["records"][0]["beam"], "| score", rec["records"][0]["beam_chain"].get("score"))
+        else:
+            rec.update(canonical=None)
+            print("G12", i, word, "-> not in cmudict (no chain)")
+        meta.append(rec)
+    np.savez_compressed(os.path.join(OUT, "g12_words.npz"), **arrays)
+    json.dump(meta, open(os.path.join(OUT, "g12_words.json"), "w"))
+
+
 # ----------------------------------------------------------------------------- G11 (SURVEY 8(f) #3: one training step)
 class GivenDropout(nn.Module):
     """nn.Dropout with the mask handed in: y = x * (mask / (1-p)), the arithmetic of ATen's dropout with a fixed noise tensor."""
@@ -686,9 +753,12 @@ def gen_train_goldens():
     """The REFERENCE model in train mode (BatchNorm on batch statistics, its Dropout modules replaced by GivenDropout with seeded
     masks), loss = nn.CTCLoss(sum)(out, targets, in_len, tgt_len) / B, loss.backward()  (AA/steps/train_ctc.py:63-76):
     log-probs, loss, every parameter gradient and the updated running statistics.  Tiny geometry in full; reference geometry
-    (H=384, 4 layers) as norms + 48 sampled entries per tensor (the tensors have 21 M elements)."""
+    (H=384, 4 layers; a short case and one with T' = 80, ragged lengths) as norms + 48 sampled entries per tensor (the tensors
+    have 21 M elements)."""
     arrays, meta = {}, []
-    for tag, g, seed, B, T, L, Lt in (("tiny", dict(synth.TINY), 11, 3, 12, 4, 2), ("ref", dict(synth.REFERENCE), 21, 2, 16, 5, 3)):
+    # "long": reference geometry at T' = 80 with ragged input / label lengths (synth_batch's default) -- BPTT over 80 steps
+    for tag, g, seed, B, T, L, Lt in (("tiny", dict(synth.TINY), 11, 3, 12, 4, 2), ("ref", dict(synth.REFERENCE), 21, 2, 16, 5, 3),
+                                      ("long", dict(synth.REFERENCE), 31, 3, 160, 9, 7)):
         geom = synth.Geometry(**g)
         sd, x, x1, masks, tg, il, tl = synth.train_case(geom, seed, B, T, L, Lt)
         m = build_reference_model(geom, sd)
@@ -723,7 +793,7 @@ def gen_train_goldens():
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ["model", "decode", "align", "eval", "ctc", "input", "chain", "aug", "train"]
+    which = sys.argv[1:] or ["model", "decode", "align", "eval", "ctc", "input", "chain", "aug", "train", "words"]
     with torch.no_grad():
         if "model" in which:
             gen_model_goldens()
@@ -743,3 +813,5 @@ if __name__ == "__main__":
         gen_aug_goldens()
     if "train" in which:
         gen_train_goldens()
+    if "words" in which:
+        gen_words_goldens()

@@ -34,10 +34,11 @@ def _bilstm(x, sd, prefix, bias, batch_first=False):
     return out
 
 
-def forward(sd_np, x, x1):
-    """Eval-mode CTC_Model.forward on CPU tensors.  sd_np: dict key -> numpy; x [B,T,F]; x1 [B,L] long."""
-    sd = {k: torch.as_tensor(v) for k, v in sd_np.items()}
-    x = torch.as_tensor(x, dtype=torch.float32)
+def forward(sd_np, x, x1, dtype=torch.float32):
+    """Eval-mode CTC_Model.forward on CPU tensors.  sd_np: dict key -> numpy; x [B,T,F]; x1 [B,L] long.  dtype=torch.float64 runs the
+    same graph in double (the yardstick for "whose fp32 evaluation is closer": tests/test_gpu_parity.py)."""
+    sd = {k: (torch.as_tensor(v).to(dtype) if np.asarray(v).dtype.kind == "f" else torch.as_tensor(v)) for k, v in sd_np.items()}
+    x = torch.as_tensor(x, dtype=dtype)
     x1 = torch.as_tensor(x1, dtype=torch.int64)
     with torch.no_grad():
         a = x.unsqueeze(1)

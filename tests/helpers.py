@@ -8,6 +8,21 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GOLD = os.path.join(ROOT, "tests", "golden")
 
 
+def record_margin(key, value, budget=None):
+    """Keep a measured distance to a tolerance: merged into gpurun_out/margins.json (scratch on the GPU box; the round's copy is
+    committed as profiles/round<N>_margins.json and cited in DESIGN.md section 2)."""
+    path = os.path.join(ROOT, "gpurun_out", "margins.json")
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    try:
+        with open(path) as f:
+            data = json.load(f)
+    except (OSError, ValueError):
+        data = {}
+    data[key] = {"measured": float(value)} if budget is None else {"measured": float(value), "budget": float(budget)}
+    with open(path, "w") as f:
+        json.dump(data, f, indent=1, sort_keys=True)
+
+
 def npz(name):
     return np.load(os.path.join(GOLD, name), allow_pickle=False)
 

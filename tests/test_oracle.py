@@ -227,7 +227,43 @@ def test_g9_benchmarked_length_and_chain(idx):
                 lambda hyp, can: diagnose(hyp, can, dec))
 
 
-@pytest.mark.parametrize("idx", [0, 1])
+def test_g12_vocabulary_single_words_through_the_oracle():
+    """G12 (the reference's chain on all 20 words of egs/vocabulary/single): the oracle's forward on the same features (oracle.fbank +
+    CMVN + stack/skip of each WAV) within 3e-6 of the reference model's posteriors, and its beam / greedy decodes + the host
+    alignment and diagnosis identical to the reference's records, for every word that has a canonical."""
+    from ctc_attention_mispronunciation_amd.utils.ctcDecoder import Decoder
+    from ctc_attention_mispronunciation_amd.utils.NgramLM import LanguageModel
+    from ctc_attention_mispronunciation_amd.infer_core import diagnose
+    import wave
+    from tests.helpers import check_chain
+    meta, g = jload("g12_words.json"), npz("g12_words.npz")
+    geom = synth.Geometry(**synth.REFERENCE)
+    sd = synth.synth_state_dict(geom, seed=11)
+    i2c = synth.phone_table_41()
+    c2i = {v: k for k, v in i2c.items()}
+    table = LanguageModel(arpa_file=os.path.join(GOLD, "lm_synth45.arpa")).dense_table(i2c, 45)
+    stats = oracle.read_cmvn_stats(os.path.join(GOLD, "global_fbank_cmvn.txt"))
+    dec = Decoder(i2c, space_idx=-1, blank_index=0)
+    n = 0
+    for rec in meta[:8]:                                          # (the oracle's forward is ~2 s per word: a subset keeps the CPU suite short)
+        if rec["canonical"] is None:
+            continue
+        w = wave.open(os.path.join(GOLD, "vocabulary_single", "%d.wav" % rec["i"]))
+        wav = np.frombuffer(w.readframes(w.getnframes()), dtype=np.int16).astype(np.float32)
+        feats = oracle.stack_skip(oracle.apply_cmvn(oracle.fbank(wav), stats))
+        x1 = np.array([[c2i[p] for p in rec["canonical"].split()]], dtype=np.int64)
+        logp = oracle.forward(sd, feats[None], x1)
+        np.testing.assert_allclose(logp, g["logp%d" % rec["i"]], rtol=0, atol=3e-6)
+        lens = [logp.shape[0]]
+        ids, st = oracle.beam(logp, lens, table, beam_width=10, alpha=0.0)
+        assert not st.any()
+        check_chain(rec["records"], [ids_to_beam_string(s, i2c) for s in ids], [ids_to_greedy_string(s, i2c) for s in oracle.greedy(logp, lens)],
+                    dec.wer, lambda hyp, can: diagnose(hyp, can, dec))
+        n += 1
+    assert n >= 6
+
+
+@pytest.mark.parametrize("idx", [0, 1, 2])
 def test_g11_train_step_restatement(idx):
     """G11: the reference model in train mode (batch-statistics BatchNorm, given dropout masks), CTCLoss(sum)/B, backward --
     log-probs, loss, every parameter gradient, updated running statistics.  This pins oracle/ref_port.train_step (the torch

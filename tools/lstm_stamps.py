@@ -10,7 +10,7 @@ for B in [int(v) for v in (sys.argv[1:] or ['64', '256'])]:
     geom = synth.Geometry(**synth.REFERENCE)
     sd = synth.synth_state_dict(geom)
     x, x1, _, _ = synth.synth_batch(geom, B=B, T=500, L=40, ragged=False)
-    m = HipModel(geom, sd)
+    m = HipModel(geom, sd, precision='bf16x3')
     x, x1 = torch.from_numpy(x).cuda(), torch.from_numpy(x1).cuda()
     for _ in range(2): m.forward(x, x1)
     torch.cuda.synchronize()

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round profile on the GPU box: the default bench line, its rocprofv3 kernel stats, the two HBM counter passes, and kernel stats
-# of the exact-fp32 mode, the CTC lattice workload and the training step.
+# of the flagged split-bf16 mode, the CTC lattice workload and the training step.
 #   gpurun -- 'bash tools/profile_round.sh <tag>'   ->  gpurun_out/<tag>_*  (copy what should be judged into profiles/)
 set -e -o pipefail
 TAG=${1:-round}
@@ -19,7 +19,7 @@ stats joint $LEAN
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/${TAG}_pmc_fetch -o ${TAG} -- python3 $R/bench.py --steps 16 --warmup 8 $LEAN --no-roofline > /dev/null 2> $OUT/${TAG}_pmc_fetch.err
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/${TAG}_pmc_write -o ${TAG} -- python3 $R/bench.py --steps 16 --warmup 8 $LEAN --no-roofline > /dev/null 2> $OUT/${TAG}_pmc_write.err
 python3 $R/tools/pmc_traffic.py $OUT/${TAG}_pmc_fetch $OUT/${TAG}_pmc_write "bench.py --steps 16 --warmup 8 (B=512 per pass)" > $OUT/${TAG}_pmc_traffic.json
-stats f32 --precision f32 --steps 16 --warmup 8 $LEAN
+stats bf16x3 --precision bf16x3 --steps 64 --warmup 16 $LEAN
 stats ctc --workload ctc256 --steps 50 --warmup 5
 stats train --workload train32 --steps 5 --warmup 2
 stats trainx3 --workload train32 --train-precision bf16x3 --steps 5 --warmup 2
