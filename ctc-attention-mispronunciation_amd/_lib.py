@@ -18,7 +18,7 @@ EXPORTS = (
     "mdd_greedy", "mdd_beam", "mdd_ctc_loss", "mdd_ctc_workspace_bytes", "mdd_align", "mdd_align_batch", "mdd_eval_batch", "mdd_fbank_num_frames", "mdd_fbank",
     "mdd_train_create", "mdd_train_destroy", "mdd_train_num_tensors", "mdd_train_tensor_info", "mdd_train_num_masks", "mdd_train_mask_bytes",
     "mdd_train_forward", "mdd_train_backward", "mdd_train_sync", "mdd_train_set_precision", "mdd_adam_step",
-    "mdd_diag_gemm_ph8", "mdd_diag_gates",
+    "mdd_diag_gemm_ph8", "mdd_diag_gates", "mdd_diag_gemm", "mdd_diag_gemm_time",
 )
 
 

@@ -44,6 +44,13 @@ int launch_gemm_bf16x3(const SplitPtr &A, const SplitPtr &W, const float *bias, 
 int init_gemm_attributes();
 int launch_split(const float *x, size_t n, const SplitPtr &out, hipStream_t st);
 int launch_unsplit(const SplitPtr &in, size_t n, float *x, hipStream_t st);
+// x [rows][ld] (K columns used) -> three bf16 planes hi | mid | lo (rows x K elements each, consecutive), hi + mid + lo == x exactly,
+// each in the K-tile-major order [K / 32][rows][32] the f32x6 kernel streams (gemm_bf16x6.hip)
+int launch_split3(const float *x, int rows, int K, int ld, unsigned short *planes, hipStream_t st);
+// C = A . W^T with fp32-grade arithmetic on the bf16 matrix cores: operands as three K-tile-major bf16 planes each (gemm_bf16x6.hip)
+int launch_gemm_f32x6(const unsigned short *A3, size_t a_plane, const unsigned short *W3, size_t w_plane, const float *bias, float *C, int M, int N, int K,
+                      int ldc, hipStream_t st, long long *stamps = nullptr);
+int init_gemm_x6_attributes();
 
 int launch_stack_skip(const float *raw, int B, int T_raw, int D, int right, int skip, int n_down, float *out,
                       hipStream_t st);

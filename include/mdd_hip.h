@@ -228,6 +228,11 @@ int mdd_adam_step(float *const *params, float *const *grads, float *const *exp_a
 int mdd_diag_gemm_ph8(int M, int N, int K, int reps, unsigned seed, unsigned *mismatches_out, float *ms_out);
 /* mdd_diag_gates: the gate nonlinearities of the reference-width recurrences (csrc/lstm_persist.h) evaluated on n device floats:
  * sig_dev[i] = sigmoid(x_dev[i]), tanh_dev[i] = tanh(x_dev[i]) (tests/test_gpu_parity.py::test_gate_functions_accuracy). */
+/* mdd_diag_gemm: C_dev[M,N] = A_dev[M,K] . W_dev[N,K]^T through one arithmetic (0 exact fp32 MFMA, 1 split-bf16 x3, 2 the f32x6
+ * prototype, 3 the f32x6 kernel), fp32 operands and result on the device; synchronises (tests/test_gpu_parity.py::test_gemm_f32x6_accuracy). */
+int mdd_diag_gemm(int mode, const float *A_dev, const float *W_dev, float *C_dev, int M, int N, int K, void *stream);
+/* mdd_diag_gemm_time: mean milliseconds of `reps` launches of one GEMM kernel on resident, pre-split pseudo-random operands. */
+int mdd_diag_gemm_time(int mode, int M, int N, int K, int reps, float *ms_out);
 int mdd_diag_gates(const float *x_dev, float *sig_dev, float *tanh_dev, int64_t n, void *stream);
 
 #ifdef __cplusplus

@@ -307,6 +307,44 @@ def test_persistent_f32_lstm_full_length_and_poisoned_input(monkeypatch):
     np.testing.assert_array_equal(bad[:, keep], ref[:, keep])
 
 
+def _gemm_modes_against_fp64(M, N, K, modes, seed=0):
+    import ctypes as C
+    from ctc_attention_mispronunciation_amd import _lib
+    L = _lib.lib()
+    L.mdd_diag_gemm.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    rng = np.random.default_rng(seed)
+    A = rng.standard_normal((M, K)).astype(np.float32)
+    A[A < 0] = 0.0                                               # post-ReLU / BatchNorm-like operands
+    A[:, ::7] *= 30.0
+    W = (rng.uniform(-1, 1, (N, K)) * 0.05).astype(np.float32)
+    ref = A.astype(np.float64) @ W.astype(np.float64).T
+    out = {"aten_f32": (torch.from_numpy(A) @ torch.from_numpy(W).T).numpy()}
+    Ad, Wd = _cuda(A), _cuda(W)
+    for name, mode in modes:
+        Cd = torch.empty((M, N), device="cuda")
+        assert L.mdd_diag_gemm(mode, Ad.data_ptr(), Wd.data_ptr(), Cd.data_ptr(), M, N, K, None) == 0, L.mdd_last_error().decode()
+        torch.cuda.synchronize()
+        out[name] = Cd.cpu().numpy()
+    scale = float(np.sqrt((ref ** 2).mean()))
+    return {k: (float(np.abs(v - ref).max()) / scale, float(np.abs(v - ref).mean()) / scale) for k, v in out.items()}
+
+
+@pytest.mark.parametrize("M,N,K", [(1024, 768, 1952), (1500, 3072, 768), (2048, 512, 512)])
+def test_gemm_f32x6_accuracy(M, N, K):
+    """One GEMM of the model's shapes through every arithmetic of the library against the float64 product, beside ATen's fp32 GEMM on
+    the CPU: the f32x6 form (three bf16 planes per operand = all 24 significand bits, six products, hi.hi in an accumulator of its
+    own) must be at least as close to float64 as ATen's fp32 -- the condition under which it stands in for fp32 arithmetic -- and
+    closer than the exact-fp32 MFMA kernel (one accumulation chain over K); split-bf16 x3 (16 significand bits) is two orders worse."""
+    from tests.helpers import record_margin
+    torch.set_num_threads(min(os.cpu_count() or 1, 16))
+    r = _gemm_modes_against_fp64(M, N, K, [("mfma_f32", 0), ("bf16x3", 1), ("f32x6_prototype", 2), ("f32x6", 3)], seed=K)
+    print("GEMM %dx%dx%d, |C - C64| / rms(C64), max and mean: " % (M, N, K) + "; ".join("%s %.2e %.2e" % (k, v[0], v[1]) for k, v in r.items()))
+    for k, v in r.items():
+        record_margin("gemm_%dx%dx%d_%s_mean_rel" % (M, N, K, k), v[1])
+    assert r["f32x6"][1] <= r["aten_f32"][1] and r["f32x6"][0] <= 1.5 * r["aten_f32"][0]
+    assert r["f32x6"][1] < r["mfma_f32"][1] < r["bf16x3"][1]
+
+
 def test_gate_functions_accuracy():
     """The short sigmoid / tanh of the reference-width recurrences (hardware exp2 / rcp + one Newton step; odd polynomial below
     |v| = 1/4) against float64 on a dense sweep and on the special values: they stay at fp32 working accuracy -- the bound asserted
