@@ -59,7 +59,7 @@ def parse():
     ap.add_argument("--hidden", type=int, default=384)
     ap.add_argument("--fuse", type=int, default=8, help="reference-sized batches carried by one launch sequence")
     ap.add_argument("--ragged", action="store_true", help="headline on the ragged set (per-batch padding, unpadded frames counted)")
-    ap.add_argument("--precision", default=None, choices=[None, "f32", "bf16x3"])
+    ap.add_argument("--precision", default=None, choices=[None, "f32", "f32x6", "bf16x3"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-variants", action="store_true", help="skip the fuse1 / ragged / f32_mode / greedy32_h256 lines")
     ap.add_argument("--gather", default="ids", choices=["ids", "posteriors", "none"],
@@ -406,6 +406,7 @@ class DecodeJob(object):
         reps = [model.profile(x, x1) for _ in range(3)]
         stages = [(reps[0][i][0], float(np.median([r[i][1] for r in reps])), reps[0][i][2], reps[0][i][3]) for i in range(len(reps[0]))]
         x3 = model.precision == "bf16x3"
+        x6 = model.precision == "f32x6"
 
         def kernel_of(name):   # which hand-written kernel a stage runs (depends on the precision mode in use)
             if name.startswith("lstm"):
@@ -413,6 +414,8 @@ class DecodeJob(object):
                     return "lstm_step_x3_kernel" if x3 else "lstm_step_packed_kernel"
                 return "lstm_layer_granule_kernel" if x3 else "lstm_layer_f32_kernel"
             if name.startswith("gemm"):
+                if x6 and name.startswith(("gemm_ih", "gemm_text")):
+                    return "gemm_f32x6_kernel"
                 if not x3:
                     return "gemm_nt_f32_kernel"
                 # launch_gemm_bf16x3's dispatch: fp32-output, unbatched, >= 1024 x 512 problems take the 256x256 8-phase kernel
@@ -425,7 +428,8 @@ class DecodeJob(object):
         cand = {k: v for k, v in groups.items() if k.startswith(("lstm_", "gemm_"))}
         kern = max(cand, key=lambda k: cand[k][0])
         ms, launches, flops = cand[kern]
-        bf16_kernel = kern in ("gemm_bf16x3_ph8_kernel", "gemm_bf16x3_glds_kernel", "lstm_layer_granule_kernel")
+        bf16_kernel = kern in ("gemm_bf16x3_ph8_kernel", "gemm_bf16x3_glds_kernel", "lstm_layer_granule_kernel", "gemm_f32x6_kernel")
+        mult = 6 if kern == "gemm_f32x6_kernel" else (3 if bf16_kernel else 1)     # bf16 MFMA flops issued per algorithmic (fp32-equivalent) flop
         peak = PEAK_BF16_MATRIX_TFLOPS if bf16_kernel else PEAK_F32_MATRIX_TFLOPS
         achieved = flops / (ms * 1e-3) / 1e12
         traffic = None
@@ -433,9 +437,9 @@ class DecodeJob(object):
             traffic = json.load(open(PMC_FILE)).get(kern)
         return {"kernel": kern, "bound": "mfma", "achieved": round(achieved, 3), "peak": peak,
                 "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic,
-                "note": ("algorithmic fp32-equivalent flops; the split-bf16 kernels issue 3 bf16 MFMA flops per algorithmic flop "
-                         "(frac x3 = matrix-core utilisation)" if bf16_kernel else "fp32 MFMA"),
-                "matrix_core_frac": round(achieved * (3 if bf16_kernel else 1) / peak, 4),
+                "note": ("algorithmic fp32-equivalent flops; this kernel issues %d bf16 MFMA flops per algorithmic flop "
+                         "(matrix_core_frac = frac x%d = matrix-core utilisation)" % (mult, mult) if bf16_kernel else "fp32 MFMA"),
+                "matrix_core_frac": round(achieved * mult / peak, 4),
                 "frac_of_fp32_mfma_peak": round(achieved / PEAK_F32_MATRIX_TFLOPS, 3),
                 "launches_per_pass": launches, "avg_launch_us": round(ms * 1e3 / max(launches, 1), 3), "batches_per_pass": G,
                 "flops_per_launch": flops / max(launches, 1),

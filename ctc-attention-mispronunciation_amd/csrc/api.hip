@@ -61,12 +61,15 @@ struct mdd_model {
     float *emb = nullptr, *t_wih = nullptr, *t_whh = nullptr, *t_bias = nullptr;
     float *w_score = nullptr, *fscale = nullptr, *fshift = nullptr, *w_fc = nullptr, *w_fcp = nullptr;
     std::vector<mdd::SplitPtr> wih_s, whh_s;                // split-bf16 copies of the GEMM / recurrent weights
+    std::vector<unsigned short *> wih_3;                    // three-plane (f32x6) copies of the input-projection weights, K-tile-major
+    unsigned short *t_wih_3 = nullptr;
     mdd::SplitPtr t_whh_s{nullptr, nullptr};
     mdd::SplitPtr t_wih_s{nullptr, nullptr}, w_score_s{nullptr, nullptr}, w_conv1_s{nullptr, nullptr};
     std::vector<void *> owned;  // every hipMalloc'd weight pointer
     // workspace
     mdd::DevBuf y0, seq0, gx, act[2], xraw, hbuf, cbuf, embo, text, key, S;
     mdd::DevBuf seq0_s, act_s[2], x_s, embo_s, text_s, key_s, hsplit, hx;   // split-bf16 activations (hi plane, then lo plane)
+    mdd::DevBuf p3;             // f32x6 mode: the three bf16 planes of the projection GEMM's A operand (rewritten per GEMM)
     std::vector<mdd::DevBuf> tap_rnn;
     int *err_flag = nullptr;
     hipStream_t cap_stream = nullptr;  // graphs are captured here (the legacy default stream cannot capture)
@@ -88,6 +91,9 @@ struct mdd_model {
     // one persistent launch per BiLSTM layer: the split-bf16 teams (lstm.hip) in mode 1, the exact-fp32 teams (lstm_f32.hip) in mode 0
     bool persist(int B) const { return lstm_persist && !lstm_x3 && packed_h() && B <= granule_max_b && (x3() || lstm_persist_f32); }
     bool lstm_persist_f32 = true;
+    bool x6() const {   // f32x6: the time-batched input projections on the bf16 matrix cores with three planes per operand; all else as mode 0
+        return precision == 2 && rnn_in() % 32 == 0 && (2 * cfg.hidden) % 32 == 0 && cfg.emb_dim % 32 == 0;
+    }
     bool x3() const {   // the bf16x3 GEMM needs K % 32 == 0 for every contraction and the packed LSTM layouts
         return precision == 1 && (cfg.hidden == 384 || cfg.hidden == 256) && rnn_in() % 32 == 0 && cfg.emb_dim % 32 == 0;
     }
@@ -241,6 +247,11 @@ static int run_stage(mdd_model *m, int si, const float *x, int B, int T, const i
                 return launch_gemm_bf16x3(in, m->wih_s[n], nullptr, m->gx.p, nullptr, Tp * B, G2, K, K, K, G2, 1, 0, 0, 0, st);
             }
             const float *in = n == 0 ? m->seq0.p : m->act[(n - 1) & 1].p;
+            if (m->x6()) {   // fp32-grade arithmetic at 6/16 of the fp32 MFMA's cost (gemm_bf16x6.hip)
+                unsigned short *p3 = reinterpret_cast<unsigned short *>(m->p3.p);
+                if (int rc = launch_split3(in, Tp * B, K, K, p3, st)) return rc;
+                return launch_gemm_f32x6(p3, (size_t)Tp * B * K, m->wih_3[n], (size_t)G2 * K, nullptr, m->gx.p, Tp * B, G2, K, G2, st);
+            }
             return launch_gemm_nt(in, m->wih[n], nullptr, m->gx.p, Tp * B, G2, K, K, K, G2, 1, 0, 0, 0, st);
         }
         snprintf(namebuf, sizeof(namebuf), "lstm%d", n); info->name = namebuf;
@@ -275,6 +286,11 @@ static int run_stage(mdd_model *m, int si, const float *x, int B, int T, const i
         info->name = "gemm_text"; info->flops = 2.0 * (double)L * B * G2 * c.emb_dim;
         if (x3) return launch_gemm_bf16x3(split_view(m->embo_s, trows * c.emb_dim), m->t_wih_s, m->t_bias, m->gx.p, nullptr, L * B, G2,
                                           c.emb_dim, c.emb_dim, c.emb_dim, G2, 1, 0, 0, 0, st);
+        if (m->x6()) {
+            unsigned short *p3 = reinterpret_cast<unsigned short *>(m->p3.p);
+            if (int rc = launch_split3(m->embo.p, L * B, c.emb_dim, c.emb_dim, p3, st)) return rc;
+            return launch_gemm_f32x6(p3, (size_t)L * B * c.emb_dim, m->t_wih_3, (size_t)G2 * c.emb_dim, m->t_bias, m->gx.p, L * B, G2, c.emb_dim, G2, st);
+        }
         return launch_gemm_nt(m->embo.p, m->t_wih, m->t_bias, m->gx.p, L * B, G2, c.emb_dim, c.emb_dim, c.emb_dim, G2, 1, 0, 0, 0, st);
     case 2: {
         info->name = "lstm_text"; info->launches = L; info->flops = 2.0 * 2 * (double)B * H * 4 * H * L;
@@ -376,6 +392,7 @@ extern "C" int mdd_create(const mdd_config *cfg, int device, mdd_model **out) {
     const char *pr = getenv("MDD_PRECISION");
     if (pr && (!strcmp(pr, "f32") || !strcmp(pr, "0"))) m->precision = 0;
     if (pr && (!strcmp(pr, "bf16x3") || !strcmp(pr, "1"))) m->precision = 1;
+    if (pr && (!strcmp(pr, "f32x6") || !strcmp(pr, "2"))) m->precision = 2;
     const char *lx = getenv("MDD_LSTM");
     m->lstm_x3 = lx && !strcmp(lx, "x3");
     if (lx && !strcmp(lx, "step")) m->lstm_persist = false;
@@ -387,6 +404,7 @@ extern "C" int mdd_create(const mdd_config *cfg, int device, mdd_model **out) {
     if (int rc = init_lstm_f32_attributes()) { delete m; return rc; }
     if (int rc = init_conv_attributes()) { delete m; return rc; }
     if (int rc = init_gemm_attributes()) { delete m; return rc; }
+    if (int rc = init_gemm_x6_attributes()) { delete m; return rc; }
     m->n_cu = prop.multiProcessorCount;
     if (!persistent_grid_fits(m->n_cu)) m->lstm_persist = false;   // per-step kernels instead (smaller partitions, other gfx950 SKUs)
     if (!persistent_f32_grid_fits(m->n_cu)) m->lstm_persist_f32 = false;
@@ -406,7 +424,7 @@ extern "C" void mdd_destroy(mdd_model *m) {
     for (auto &kv : m->graphs) (void)hipGraphExecDestroy(kv.second);
     for (void *p : m->owned) (void)hipFree(p);
     DevBuf *bufs[] = {&m->y0, &m->seq0, &m->gx, &m->act[0], &m->act[1], &m->xraw, &m->hbuf, &m->cbuf, &m->embo, &m->text, &m->key, &m->S,
-                      &m->seq0_s, &m->act_s[0], &m->act_s[1], &m->x_s, &m->embo_s, &m->text_s, &m->key_s, &m->hsplit, &m->hx, &m->xstack};
+                      &m->seq0_s, &m->act_s[0], &m->act_s[1], &m->x_s, &m->embo_s, &m->text_s, &m->key_s, &m->hsplit, &m->hx, &m->xstack, &m->p3};
     for (DevBuf *b : bufs) if (b->p) (void)hipFree(b->p);
     for (auto &b : m->tap_rnn) if (b.p) (void)hipFree(b.p);
     if (m->err_flag) (void)hipFree(m->err_flag);
@@ -433,7 +451,7 @@ extern "C" int mdd_finalize_weights(mdd_model *m) {
     const int ch = c.channels, H = c.hidden;
     int rc;
     for (void *p : m->owned) (void)hipFree(p);
-    m->owned.clear(); m->wih.clear(); m->whh.clear(); m->wih_s.clear(); m->whh_s.clear();
+    m->owned.clear(); m->wih.clear(); m->whh.clear(); m->wih_s.clear(); m->whh_s.clear(); m->wih_3.clear(); m->t_wih_3 = nullptr;
     m->bn_scale.assign(c.layers, nullptr); m->bn_shift.assign(c.layers, nullptr);
     for (auto &kv : m->graphs) (void)hipGraphExecDestroy(kv.second);
     m->graphs.clear();
@@ -468,6 +486,13 @@ extern "C" int mdd_finalize_weights(mdd_model *m) {
         if ((rc = upload(m, tmp, &d))) return rc;
         m->wih.push_back(d);
         { SplitPtr sp{nullptr, nullptr}; if ((rc = upload_split(m, tmp, &sp))) return rc; m->wih_s.push_back(sp); }
+        if (K % 32 == 0) {   // f32x6: hi | mid | lo planes in the kernel's K-tile-major order, made on the device from the fp32 copy
+            unsigned short *p3 = nullptr;
+            MDD_HIP_CHECK(hipMalloc((void **)&p3, (size_t)3 * 8 * H * K * sizeof(unsigned short)));
+            m->owned.push_back(p3);
+            if ((rc = launch_split3(d, 8 * H, K, K, p3, nullptr))) return rc;
+            m->wih_3.push_back(p3);
+        } else m->wih_3.push_back(nullptr);
         if (!pack_gate_rows(m, base, "weight_hh_l0", H, H, tmp)) return MDD_ERR_STATE;
         { SplitPtr sp{nullptr, nullptr}; if ((rc = upload_split(m, tmp, &sp))) return rc; m->whh_s.push_back(sp); }
         if (use_packed(m)) { std::vector<float> pk; pack_whh(tmp, H, pk); tmp.swap(pk); }
@@ -485,6 +510,11 @@ extern "C" int mdd_finalize_weights(mdd_model *m) {
         if ((rc = upload(m, *e, &m->emb))) return rc;
         if (!pack_gate_rows(m, "lstm_embeds.", "weight_ih_l0", H, c.emb_dim, tmp)) return MDD_ERR_STATE;
         if ((rc = upload(m, tmp, &m->t_wih)) || (rc = upload_split(m, tmp, &m->t_wih_s))) return rc;
+        if (c.emb_dim % 32 == 0) {
+            MDD_HIP_CHECK(hipMalloc((void **)&m->t_wih_3, (size_t)3 * 8 * H * c.emb_dim * sizeof(unsigned short)));
+            m->owned.push_back(m->t_wih_3);
+            if ((rc = launch_split3(m->t_wih, 8 * H, c.emb_dim, c.emb_dim, m->t_wih_3, nullptr))) return rc;
+        }
         if (!pack_gate_rows(m, "lstm_embeds.", "weight_hh_l0", H, H, tmp)) return MDD_ERR_STATE;
         if ((rc = upload_split(m, tmp, &m->t_whh_s))) return rc;
         if (use_packed(m)) { std::vector<float> pk; pack_whh(tmp, H, pk); tmp.swap(pk); }
@@ -531,7 +561,7 @@ extern "C" int mdd_enable_taps(mdd_model *m, int32_t on) {
 }
 
 extern "C" int mdd_set_precision(mdd_model *m, int32_t mode) {
-    if (!m || (mode != 0 && mode != 1)) { set_error("mdd_set_precision: mode must be 0 (fp32 MFMA) or 1 (split-bf16 x3)"); return MDD_ERR_ARG; }
+    if (!m || mode < 0 || mode > 2) { set_error("mdd_set_precision: mode must be 0 (fp32 MFMA), 1 (split-bf16 x3) or 2 (f32x6 projections)"); return MDD_ERR_ARG; }
     if (m->precision != mode) {
         m->precision = mode;
         for (auto &kv : m->graphs) (void)hipGraphExecDestroy(kv.second);
@@ -539,7 +569,7 @@ extern "C" int mdd_set_precision(mdd_model *m, int32_t mode) {
     }
     return MDD_OK;
 }
-extern "C" int32_t mdd_get_precision(mdd_model *m) { return m ? (m->x3() ? 1 : 0) : -1; }
+extern "C" int32_t mdd_get_precision(mdd_model *m) { return m ? (m->x3() ? 1 : (m->x6() ? 2 : 0)) : -1; }
 
 extern "C" int mdd_stack_skip(const float *raw_dev, int32_t B, int32_t T_raw, int32_t D, int32_t right, int32_t skip,
                               int32_t n_down, float *out_dev, void *stream) {
@@ -570,6 +600,11 @@ static int forward_prepare(mdd_model *m, const float *x_dev, int32_t B, int32_t 
                     (rc = ensure(m->embo_s, trows * c.emb_dim, zs)) || (rc = ensure(m->text_s, trows * 2 * H, zs)) ||
                     (rc = ensure(m->key_s, trows * 2 * H, zs)) || (rc = ensure(m->hsplit, (size_t)4 * B * H, zs))))
         return rc;
+    {   // f32x6: three bf16 planes of the largest projection operand = 1.5 x its fp32 size (in floats: 3/2)
+        const size_t kmax = (size_t)(m->rnn_in() > 2 * H ? m->rnn_in() : 2 * H), k2 = (size_t)c.emb_dim;
+        const size_t need = (rows * kmax > trows * k2 ? rows * kmax : trows * k2) * 3 / 2 + 64;
+        if (m->x6() && (rc = ensure(m->p3, need, zs))) return rc;
+    }
     if (m->persist(B) && (rc = ensure(m->hx, (size_t)2 * 32 * granule_bg(B) * H * 2 + 64 + 256 * 6 * 2, zs))) return rc;   // the exchange buffer of the persistent layers (u64 granules) + stamps
     if (m->taps) {
         m->tap_rnn.resize(c.layers);

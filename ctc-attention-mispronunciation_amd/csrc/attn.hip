@@ -257,7 +257,8 @@ __global__ __launch_bounds__(256, 2) void attn_tail_mfma_kernel(const float *__r
     // 3. classifier: this wave's quarter of K, three 16-column tiles
     {
         const float *yr = yc + li * LDY + (xhalf ? 0 : wave - 2) * (D2 / 4) + 4 * kq;   // context half (waves 2, 3)
-        f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0;
+        // two-level accumulation (see gemm.hip, SEG): 16 roundings per segment, then one per segment, instead of a chain of D2 / 16
+        f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0, t0 = a0, t1 = a0, t2 = a0;
         for (int j0 = 0; j0 < J; j0 += 4) {
             float4 y4[4], w0[4], w1[4], w2[4];
 #pragma unroll
@@ -287,7 +288,10 @@ __global__ __launch_bounds__(256, 2) void attn_tail_mfma_kernel(const float *__r
                 a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(y4[u].w, w1[u].w, a1, 0, 0, 0);
                 a2 = __builtin_amdgcn_mfma_f32_16x16x4f32(y4[u].w, w2[u].w, a2, 0, 0, 0);
             }
+            t0 += a0; t1 += a1; t2 += a2;
+            a0 = (f32x4){0.f, 0.f, 0.f, 0.f}; a1 = a0; a2 = a0;
         }
+        a0 = t0; a1 = t1; a2 = t2;
         float *pw = part + wave * 16 * 48;
 #pragma unroll
         for (int r = 0; r < 4; r++) {   // D: row (time) = 4*(lane>>4)+r, col (class) = lane&15

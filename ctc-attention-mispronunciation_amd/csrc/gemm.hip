@@ -52,7 +52,13 @@ __device__ __forceinline__ void store_tile_lds(float *s, int tid, const float4 (
     }
 }
 
-template <bool ALIGNED>
+// SEG: two-level accumulation.  An MFMA accumulator is ONE rounding per two products along K; over K = 768 that chain's rounding noise
+// was the largest contribution to the attention scores' (and through them the log-probs') distance from a float64 evaluation
+// (tools/stage_errors.py: key 4.6e-7 of rms against ATen's 3.5e-7).  With SEG the accumulators are emptied into a second set every four
+// K-tiles (32 roundings per segment, then one per segment): measured below ATen's blocked CPU GEMM.  The adds are vector
+// instructions an fp32 MFMA does not hide (~6 % of the kernel), so the large input projections (N > 1024), which have their own
+// fp32-grade form on the bf16 matrix cores (gemm_bf16x6.hip), keep the single chain; the choice depends on the shape only.
+template <bool ALIGNED, bool SEG>
 __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(const float *__restrict__ A, const float *__restrict__ W,
                                                           const float *__restrict__ bias, float *__restrict__ C, int M,
                                                           int N, int K, int lda, int ldw, int ldc, long sA, long sW,
@@ -69,13 +75,13 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(const float *__restric
     const int m0 = tm * BM, n0 = tn * BN;
     A += (size_t)blockIdx.z * sA; W += (size_t)blockIdx.z * sW; C += (size_t)blockIdx.z * sC;
 
-    f32x16 acc[2][2];
+    f32x16 acc[2][2], tot[2][2];
 #pragma unroll
     for (int i = 0; i < 2; i++)
 #pragma unroll
         for (int j = 0; j < 2; j++)
 #pragma unroll
-            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+            for (int r = 0; r < 16; r++) { acc[i][j][r] = 0.f; tot[i][j][r] = 0.f; }
 
     float4 ra[2], rw[2];
     load_tile_regs<ALIGNED>(A, lda, M, K, m0, 0, tid, ra);
@@ -107,6 +113,14 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(const float *__restric
             store_tile_lds(lds[cur ^ 1][0], tid, ra);
             store_tile_lds(lds[cur ^ 1][1], tid, rw);
         }
+        if (SEG && (kt & 3) == 3) {
+#pragma unroll
+            for (int i = 0; i < 2; i++)
+#pragma unroll
+                for (int j = 0; j < 2; j++)
+#pragma unroll
+                    for (int r = 0; r < 16; r++) { tot[i][j][r] += acc[i][j][r]; acc[i][j][r] = 0.f; }
+        }
         __syncthreads();
     }
 
@@ -121,7 +135,7 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(const float *__restric
 #pragma unroll
             for (int r = 0; r < 16; r++) {
                 int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (row < M) C[(size_t)row * ldc + col] = acc[i][j][r] + bv;
+                if (row < M) C[(size_t)row * ldc + col] = (SEG ? tot[i][j][r] + acc[i][j][r] : acc[i][j][r]) + bv;
             }
         }
 }
@@ -133,10 +147,11 @@ int launch_gemm_nt(const float *A, const float *W, const float *bias, float *C, 
     dim3 grid(tiles_m * tiles_n, 1, batch), block(256);
     bool aligned = (lda % 4 == 0) && (ldw % 4 == 0) && (sA % 4 == 0) && (sW % 4 == 0) &&
                    ((uintptr_t)A % 16 == 0) && ((uintptr_t)W % 16 == 0);
-    if (aligned)
-        hipLaunchKernelGGL(gemm_nt_f32_kernel<true>, grid, block, 0, st, A, W, bias, C, M, N, K, lda, ldw, ldc, sA, sW, sC, tiles_n);
-    else
-        hipLaunchKernelGGL(gemm_nt_f32_kernel<false>, grid, block, 0, st, A, W, bias, C, M, N, K, lda, ldw, ldc, sA, sW, sC, tiles_n);
+    const bool seg = N <= 1024 && K > 64;
+    if (aligned && seg) hipLaunchKernelGGL((gemm_nt_f32_kernel<true, true>), grid, block, 0, st, A, W, bias, C, M, N, K, lda, ldw, ldc, sA, sW, sC, tiles_n);
+    else if (aligned) hipLaunchKernelGGL((gemm_nt_f32_kernel<true, false>), grid, block, 0, st, A, W, bias, C, M, N, K, lda, ldw, ldc, sA, sW, sC, tiles_n);
+    else if (seg) hipLaunchKernelGGL((gemm_nt_f32_kernel<false, true>), grid, block, 0, st, A, W, bias, C, M, N, K, lda, ldw, ldc, sA, sW, sC, tiles_n);
+    else hipLaunchKernelGGL((gemm_nt_f32_kernel<false, false>), grid, block, 0, st, A, W, bias, C, M, N, K, lda, ldw, ldc, sA, sW, sC, tiles_n);
     MDD_LAUNCH_CHECK();
     return MDD_OK;
 }

@@ -83,22 +83,32 @@ __global__ void add3_kernel(float *__restrict__ c, const float *__restrict__ s1,
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) c[i] = c[i] + (s1[i] + s2[i]);
 }
 
-// ---- the kernel: 192 x 128 tile of C per workgroup, FOUR waves (one per SIMD, 512 registers each) of 96 x 64, K-tile 32.
-// Three accumulator sets of 6 x 4 MFMA tiles per wave -- hh (hi.hi), sm (the five small products), tot (hh flushed into it every
-// FLUSH K-tiles, which keeps the hh chain at FLUSH roundings per segment: at K = 1952 one chain of 61 was measured at 1.3x ATen's
-// error, segments of 8 are below it) -- are what the one-wave-per-SIMD shape is for: 288 accumulator registers fit 512, not 256.
-// Operands stream HBM -> LDS with LDS-DMA (16 B per lane, XOR-swizzled on the source side so that fragment reads are
-// conflict-free: the layout of gemm_bf16x3.hip), two stages of 60 KB; a K-tile's 15 pieces per wave go out three at a time between the
-// row tiles of the K-tile before; one workgroup barrier per K-tile.  The W fragment is the MFMA's first operand, so a lane's four
-// accumulator registers are four consecutive columns of one C row and the tile leaves as 16-byte stores.
+// ---- the kernel: 192 x 128 tile of C per workgroup, FOUR waves (one per SIMD, 512 registers each), K-tile 32.
+// A wave owns 48 rows x all 128 columns: 3 x 8 MFMA tiles x THREE accumulator sets -- hh (hi.hi), sm (the five small products), tot (hh
+// flushed into it every X6_FLUSH K-tiles: at K = 1952 one chain of 61 roundings was measured at 1.3x ATen's error, segments of 8
+// are below it) = 288 accumulator registers, which is what the one-wave-per-SIMD shape is for.
+// Operand paths (what the first forms of this kernel taught, profiles/round3_gemm_f32x6_notes.txt):
+//  * A: a wave's rows are nobody else's, so its A fragments never touch LDS: nine 16-byte-per-lane global loads per K-tile straight into
+//    registers, issued a whole K-tile ahead.  The planes are K-tile-major (launch_split3), so one load instruction is 1 KB of
+//    contiguous memory in fragment order.
+//  * W: shared by the four waves, streamed HBM/L2 -> LDS by LDS-DMA (24 KB per K-tile, six pieces per wave, XOR-swizzled on the
+//    source side so that fragment reads are conflict-free), two stages; fragments are read two column tiles at a time, one pair ahead of
+//    the MFMAs that use them -- never in a burst: four waves reading a K-tile's worth of fragments at once behind a barrier took
+//    ~780 cycles (LDS bandwidth), a third of the K-tile's MFMA time.
+//  * every memory instruction goes out alone between MFMA groups (a burst stalls the issuing wave, and with one wave per SIMD nobody
+//    else feeds the matrix pipe meanwhile); one vmcnt(0) + barrier per K-tile, a whole K-tile after the requests.
+// The two MFMA-fed accumulator sets live in the accumulation file ("+a" asm MFMAs: the compiler otherwise shuttles a set between the
+// files on every K-tile) and the flush sits between two loops, not in a conditional inside one (same reason).  The W fragment is the
+// MFMA's first operand, so a lane's four accumulator registers are four consecutive columns of one C row: 16-byte stores.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void lds_void6;
-constexpr int X6_RT = 6;                                              // 16-row MFMA tiles per wave: 6 x 4 tiles x 3 accumulator sets = 288 registers (8 would need 384 + fragments: spills)
-constexpr int X6_BM = 2 * 16 * X6_RT, X6_BN = 128, X6_BK = 32, X6_ROW = 64;   // X6_ROW: bytes per LDS row (32 bf16)
-constexpr int X6_GA = X6_BM / 16 / 4, X6_NP = 3 * X6_GA + 6;         // A row groups (16 rows) per wave; LDS-DMA pieces per wave and K-tile
-constexpr int X6_PA = X6_BM * X6_ROW, X6_PW = X6_BN * X6_ROW;          // bytes per A / W plane of a stage
-constexpr int X6_STAGE = 3 * X6_PA + 3 * X6_PW;                       // 72 KB
+constexpr int X6_RT = 3;                                              // 16-row MFMA tiles per wave
+constexpr int X6_BM = 4 * 16 * X6_RT, X6_BN = 128, X6_BK = 32, X6_ROW = 64;   // X6_ROW: bytes per LDS row (32 bf16)
+constexpr int X6_PW = X6_BN * X6_ROW;                                 // bytes per W plane of a stage (8 KB)
+constexpr int X6_STAGE = 3 * X6_PW;                                   // 24 KB
+constexpr int X6_NS = 2;                                              // stages
+constexpr int X6_NPW = 3 * (X6_BN / 16) / 4;                          // LDS-DMA pieces per wave and K-tile (6)
 constexpr int X6_FLUSH = 8;
 
 __device__ __forceinline__ bf16x8 x6_frag(const unsigned char *plane, int row, int kbyte) {
@@ -109,155 +119,134 @@ template <bool STAMP>
 __global__ __launch_bounds__(256, 1) void gemm_f32x6_kernel(const unsigned short *__restrict__ Ap, const unsigned short *__restrict__ Wp, size_t a_plane, size_t w_plane,
                                                             const float *__restrict__ bias, float *__restrict__ C, int M, int N, int K, int ldc, int tiles_n,
                                                             long long *stamps) {
-    // STAMP (diagnostic instantiation): per wave, cycles of the K loop spent issuing the next stage + reading the first fragments / in the
-    // MFMA section / waiting for the LDS-DMA / at the barrier -> stamps[(workgroup * 4 + wave) * 4 + {0..3}] (tools/gemm_time.py)
+    // STAMP (diagnostic instantiation): per wave, cycles of the K loop in the MFMA stream / waiting for memory / at the barrier
+    // -> stamps[(workgroup * 4 + wave) * 4 + {0, 1, 2}] (tools/gemm_time.py)
     long long sacc[4] = {0, 0, 0, 0}, stt = 0;
 #define X6_T(i_) do { if (STAMP) { const long long n_ = (long long)__builtin_readcyclecounter(); sacc[i_] += n_ - stt; stt = n_; } } while (0)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem6[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wave >> 1, wc = wave & 1;
     int nwg = gridDim.x, bid = blockIdx.x;
     int q = nwg >> 3, rem = nwg & 7, xcd = bid & 7;
     int swz = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + (bid >> 3);   // an XCD walks consecutive tiles: the A panel stays in its L2
     const int tm = swz / tiles_n, tn = swz % tiles_n;
-    const int m0 = tm * X6_BM, n0 = tn * X6_BN;
-    f32x4 hh[X6_RT][4], sm[X6_RT][4], tot[X6_RT][4];
+    const int m0 = tm * X6_BM + wave * (16 * X6_RT), n0 = tn * X6_BN;      // this wave's first row; the workgroup's first column
+    f32x4 hh[X6_RT][8], sm[X6_RT][8], tot[X6_RT][8];
 #pragma unroll
     for (int i = 0; i < X6_RT; i++)
 #pragma unroll
-        for (int j = 0; j < 4; j++) { hh[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; sm[i][j] = hh[i][j]; tot[i][j] = hh[i][j]; }
-    // LDS-DMA pieces of this wave: A row groups GA*w .. GA*w+GA-1 and W row groups 2w, 2w+1 (16 rows each), three planes each.  Per-lane byte
-    // offsets are fixed for the whole K loop; the plane and k0 go into the scalar base.
-    const unsigned lds0 = (unsigned)(unsigned long long)(lds_void6 *)smem6;
-    unsigned voffA[X6_GA], voffW[2];
+        for (int j = 0; j < 8; j++) { hh[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; sm[i][j] = hh[i][j]; tot[i][j] = hh[i][j]; }
+    const int l16 = lane & 15, kq = lane >> 4;
+    // A fragments straight from the K-tile-major planes: lane (row l16 of row tile i, k-slice kq) reads 16 bytes at ((kt * M + row) * 32 + kq * 8)
+    // elements; rows past M are clamped (their C rows are never stored)
+    unsigned aoff[X6_RT];
 #pragma unroll
-    for (int g = 0; g < X6_GA; g++) {
-        const int row = (wave * X6_GA + g) * 16 + (lane >> 2), c = (lane & 3) ^ ((row >> 2) & 3);
-        voffA[g] = (unsigned)(((size_t)min(m0 + row, M - 1) * 32 + c * 8) * 2);      // K-tile-major planes: 64 bytes per row and K-tile
-    }
+    for (int i = 0; i < X6_RT; i++) aoff[i] = (unsigned)(((size_t)min(m0 + i * 16 + l16, M - 1) * 32 + kq * 8) * 2);
+    auto load_a = [&](bf16x8 (&fa)[X6_RT][3], int kt) {
+#pragma unroll
+        for (int p = 0; p < 3; p++) {
+            const unsigned char *base = reinterpret_cast<const unsigned char *>(Ap + (size_t)p * a_plane + (size_t)kt * M * 32);
+#pragma unroll
+            for (int i = 0; i < X6_RT; i++) fa[i][p] = *reinterpret_cast<const bf16x8 *>(base + aoff[i]);
+        }
+    };
+    // W: LDS-DMA pieces of this wave = row groups 2w, 2w+1 (16 rows each) of the three planes
+    const unsigned lds0 = (unsigned)(unsigned long long)(lds_void6 *)smem6;
+    unsigned voffW[2];
 #pragma unroll
     for (int g = 0; g < 2; g++) {
         const int row = (wave * 2 + g) * 16 + (lane >> 2), c = (lane & 3) ^ ((row >> 2) & 3);
         voffW[g] = (unsigned)(((size_t)min(n0 + row, N - 1) * 32 + c * 8) * 2);
     }
-    auto piece = [&](int idx, int kt_, unsigned stage_off) {   // idx < 3 GA: A (plane idx / GA, group idx % GA); then W (plane (idx - 3 GA) / 2, group (idx - 3 GA) % 2)
-        if (idx < 3 * X6_GA) {
-            const int p = idx / X6_GA, g = idx % X6_GA;
-            const unsigned short *base = Ap + (size_t)p * a_plane + (size_t)kt_ * M * 32;
-            const unsigned la = lds0 + stage_off + (unsigned)(p * X6_PA + (wave * X6_GA + g) * 1024);
-            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(voffA[g]), "s"(base), "s"(la) : "memory", "m0");
-        } else {
-            const int p = (idx - 3 * X6_GA) >> 1, g = (idx - 3 * X6_GA) & 1;
-            const unsigned short *base = Wp + (size_t)p * w_plane + (size_t)kt_ * N * 32;
-            const unsigned la = lds0 + stage_off + (unsigned)(3 * X6_PA + p * X6_PW + (wave * 2 + g) * 1024);
-            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(voffW[g]), "s"(base), "s"(la) : "memory", "m0");
-        }
+    auto piece = [&](int idx, int kt_, unsigned stage_off) {   // idx 0..5: plane idx / 2, row group idx % 2
+        const int p = idx >> 1, g = idx & 1;
+        const unsigned short *base = Wp + (size_t)p * w_plane + (size_t)kt_ * N * 32;
+        const unsigned la = lds0 + stage_off + (unsigned)(p * X6_PW + (wave * 2 + g) * 1024);
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(voffW[g]), "s"(base), "s"(la) : "memory", "m0");
     };
     const int nk = K / X6_BK;
-    const int l16 = lane & 15, kq16 = (lane >> 4) * 16;
+    const int kq16 = kq * 16;
+    bf16x8 faA[X6_RT][3], faB[X6_RT][3];
 #pragma unroll
-    for (int idx = 0; idx < X6_NP; idx++) piece(idx, 0, 0u);
+    for (int idx = 0; idx < X6_NPW; idx++) piece(idx, 0, 0u);
+    load_a(faA, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_waitcnt(0x0F70);
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    // One K-tile.  Its W fragments (fwc) and the A fragments of its first row tile (fa[0]) are already in registers: they were read
-    // under the LAST row tile of the K-tile before, right behind the barrier that declared this stage complete -- so neither the
-    // fragment reads' LDS latency (measured 780 cycles with all four waves reading at once behind a K-tile-end barrier) nor the
-    // barrier's skew stand between two K-tiles' MFMAs.  The next stage's LDS-DMA pieces go out ONE at a time, one per MFMA group of the
-    // first X6_IS row tiles (a burst of pieces stalls the issuing wave, and with one wave per SIMD nobody else feeds the matrix pipe
-    // meanwhile; later than that they would not have landed when the last row tile starts).
-    // The two MFMA-fed accumulator sets live in the accumulation file for the whole K loop ("+a": written as asm because the compiler
-    // otherwise shuttles one set between the files on every K-tile); tot is only touched by the flush's vector adds.
-    bf16x8 fa[2][3];
-    constexpr int X6_IS = 3;                                             // row tiles over which the next stage is requested
-    static_assert(X6_IS * 6 >= X6_NP && (X6_RT % 2) == 0, "one piece per MFMA group at most; fa[0] must be free under the last row tile");
 #define X6_MFMA(acc_, w_, a_) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc_) : "v"(w_), "v"(a_))
-    auto ktile = [&](int kt, bf16x8 (&fwc)[3][4], bf16x8 (&fwn)[3][4]) {
-        const unsigned char *st = smem6 + (kt & 1) * X6_STAGE;
-        const unsigned char *nsp = smem6 + ((kt & 1) ^ 1) * X6_STAGE;
-        const unsigned nst = (unsigned)(((kt & 1) ^ 1) * X6_STAGE);
+    // One K-tile: fac holds its A fragments, fan receives the next K-tile's.  Column tiles in pairs (jp): the pair's six W fragments are read
+    // from LDS one pair ahead; per pair 3 rows x 2 columns x 6 products = 36 MFMAs, product-major (six different accumulators in a row),
+    // smallest products first, hi.hi last and into its own accumulator.
+    auto ktile = [&](int kt, bf16x8 (&fac)[X6_RT][3], bf16x8 (&fan)[X6_RT][3]) {
+        const unsigned char *st = smem6 + (kt % X6_NS) * X6_STAGE;
+        const unsigned nst = (unsigned)(((kt + 1) % X6_NS) * X6_STAGE);
         const bool more = kt + 1 < nk;
+        bf16x8 fw[2][3][2];
 #pragma unroll
-        for (int i = 0; i < X6_RT; i++) {
-            if (i + 1 < X6_RT) {
+        for (int p = 0; p < 3; p++)
 #pragma unroll
-                for (int p = 0; p < 3; p++) fa[(i + 1) & 1][p] = x6_frag(st + p * X6_PA, wr * (16 * X6_RT) + (i + 1) * 16 + l16, kq16);
-            } else if (more) {
-                X6_T(0);
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // this wave's pieces of the next stage have landed
-                X6_T(1);
-                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // ... everybody's; and every wave has read all it needs of this stage
-                X6_T(2);
+            for (int jj = 0; jj < 2; jj++) fw[0][p][jj] = x6_frag(st + p * X6_PW, jj * 16 + l16, kq16);
+#pragma unroll
+        for (int jp = 0; jp < 4; jp++) {
+            if (jp + 1 < 4) {
 #pragma unroll
                 for (int p = 0; p < 3; p++)
 #pragma unroll
-                    for (int j = 0; j < 4; j++) fwn[p][j] = x6_frag(nsp + 3 * X6_PA + p * X6_PW, wc * 64 + j * 16 + l16, kq16);
-#pragma unroll
-                for (int p = 0; p < 3; p++) fa[0][p] = x6_frag(nsp + p * X6_PA, wr * (16 * X6_RT) + l16, kq16);
+                    for (int jj = 0; jj < 2; jj++) fw[(jp + 1) & 1][p][jj] = x6_frag(st + p * X6_PW, ((jp + 1) * 2 + jj) * 16 + l16, kq16);
             }
-            const bf16x8 ah = fa[i & 1][0], am = fa[i & 1][1], al = fa[i & 1][2];
-            // small products first (smallest first), hi.hi last and into its own accumulator; product-major so that consecutive MFMAs
-            // write different accumulators
-#define X6_PIECE(g_) do { if (i < X6_IS) { const int pi_ = (i * 6 + (g_)) * X6_NP / (X6_IS * 6), pn_ = (i * 6 + (g_) + 1) * X6_NP / (X6_IS * 6); if (more && pn_ > pi_) piece(pi_, kt + 1, nst); } } while (0)
-            X6_PIECE(0);
-#pragma unroll
-            for (int j = 0; j < 4; j++) X6_MFMA(sm[i][j], fwc[1][j], am);
-            X6_PIECE(1);
-#pragma unroll
-            for (int j = 0; j < 4; j++) X6_MFMA(sm[i][j], fwc[2][j], ah);
-            X6_PIECE(2);
-#pragma unroll
-            for (int j = 0; j < 4; j++) X6_MFMA(sm[i][j], fwc[0][j], al);
-            X6_PIECE(3);
-#pragma unroll
-            for (int j = 0; j < 4; j++) X6_MFMA(sm[i][j], fwc[1][j], ah);
-            X6_PIECE(4);
-#pragma unroll
-            for (int j = 0; j < 4; j++) X6_MFMA(sm[i][j], fwc[0][j], am);
-            X6_PIECE(5);
-#pragma unroll
-            for (int j = 0; j < 4; j++) X6_MFMA(hh[i][j], fwc[0][j], ah);
-#undef X6_PIECE
+            // memory instructions of the next K-tile, one per product group: 9 A fragment loads (pairs 0, 1), 6 W pieces (pairs 1, 2)
+#define X6_MEM(g_) do { if (more) { const int s_ = jp * 6 + (g_); \
+                if (s_ < 9) { const int p_ = s_ / X6_RT, i_ = s_ % X6_RT; \
+                    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(fan[i_][p_]) : "v"(aoff[i_]), "s"(Ap + (size_t)p_ * a_plane + (size_t)(kt + 1) * M * 32) : "memory"); } \
+                else if (s_ < 9 + X6_NPW) piece(s_ - 9, kt + 1, nst); } } while (0)
+#define X6_GROUP(acc_, wp_, ap_) _Pragma("unroll") for (int i = 0; i < X6_RT; i++) { _Pragma("unroll") for (int jj = 0; jj < 2; jj++) X6_MFMA(acc_[i][jp * 2 + jj], fw[jp & 1][wp_][jj], fac[i][ap_]); }
+            X6_MEM(0); X6_GROUP(sm, 1, 1)      // mid . mid
+            X6_MEM(1); X6_GROUP(sm, 2, 0)      // W lo . A hi
+            X6_MEM(2); X6_GROUP(sm, 0, 2)      // W hi . A lo
+            X6_MEM(3); X6_GROUP(sm, 1, 0)      // W mid . A hi
+            X6_MEM(4); X6_GROUP(sm, 0, 1)      // W hi . A mid
+            X6_MEM(5); X6_GROUP(hh, 0, 0)      // hi . hi
+#undef X6_GROUP
+#undef X6_MEM
         }
+        X6_T(0);
+        // The next K-tile's A fragments and this wave's W pieces (requested a K-tile ago) are here.  The A loads are asm as well: as C++
+        // loads the compiler's wait-count pass, which cannot see the asm LDS-DMA pieces, guarded the next K-tile's first MFMAs with
+        // vmcnt(1) / vmcnt(0) that also waited for the loads issued a few instructions earlier (a memory round trip per K-tile).
+        // Nothing reads or moves the destination registers before this wait (checked in the ISA: the registers the loads write are the
+        // ones the next K-tile's MFMAs read).
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        X6_T(1);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // ... everybody's pieces; and every wave is done reading this stage
+        X6_T(2);
     };
-    bf16x8 fwA[3][4], fwB[3][4];
-#pragma unroll
-    for (int p = 0; p < 3; p++)
-#pragma unroll
-        for (int j = 0; j < 4; j++) fwA[p][j] = x6_frag(smem6 + 3 * X6_PA + p * X6_PW, wc * 64 + j * 16 + l16, kq16);
-#pragma unroll
-    for (int p = 0; p < 3; p++) fa[0][p] = x6_frag(smem6 + p * X6_PA, wr * (16 * X6_RT) + l16, kq16);
     if (STAMP) stt = (long long)__builtin_readcyclecounter();
-    // Segments of X6_FLUSH K-tiles with the flush of hh into tot BETWEEN them (as a conditional inside one K loop the compiler kept a copy
-    // of hh in ordinary registers across every K-tile: 96 v_accvgpr_read + 96 v_accvgpr_write per 144 MFMAs); K-tiles in pairs, so that
-    // the two W fragment sets swap roles without a register copy.
-    static_assert(X6_FLUSH % 2 == 0, "K-tiles are taken in pairs");
+    // Segments of X6_FLUSH K-tiles with the flush of hh into tot BETWEEN them; K-tiles in pairs, so that the two A fragment sets swap roles
+    // without a register copy.
+    static_assert(X6_FLUSH % 2 == 0 && X6_NS == 2, "K-tiles are taken in pairs");
     for (int kt0 = 0; kt0 < nk; kt0 += X6_FLUSH) {
         const int kt1 = min(kt0 + X6_FLUSH, nk);
         for (int kt = kt0; kt < kt1; kt += 2) {
-            ktile(kt, fwA, fwB);
-            if (kt + 1 < kt1) ktile(kt + 1, fwB, fwA);
-            else {   // an odd tail: the loop ends here (kt1 == nk); nothing follows that would read fwA / fwB in the wrong role
-            }
+            ktile(kt, faA, faB);
+            if (kt + 1 < kt1) ktile(kt + 1, faB, faA);
         }
         asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");                     // the asm MFMAs' results are read by vector instructions next: their wait states by hand
 #pragma unroll
         for (int i = 0; i < X6_RT; i++)
 #pragma unroll
-            for (int j = 0; j < 4; j++) { tot[i][j] += hh[i][j]; hh[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+            for (int j = 0; j < 8; j++) { tot[i][j] += hh[i][j]; hh[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
     }
 #undef X6_MFMA
-    X6_T(3);
     if (STAMP && stamps && lane == 0 && blockIdx.x < 1024)
         for (int i = 0; i < 4; i++) stamps[((size_t)blockIdx.x * 4 + wave) * 4 + i] = sacc[i];
 #undef X6_T
     asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
-    const int q4 = (lane >> 4) * 4;   // D row = 4 * (lane >> 4) + r = C column, D col = lane & 15 = C row
+    const int q4 = kq * 4;   // D row = 4 * (lane >> 4) + r = C column, D col = lane & 15 = C row
 #pragma unroll
     for (int i = 0; i < X6_RT; i++) {
-        const int row = m0 + wr * (16 * X6_RT) + i * 16 + l16;
+        const int row = m0 + i * 16 + l16;
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const int col = n0 + wc * 64 + j * 16 + q4;
+        for (int j = 0; j < 8; j++) {
+            const int col = n0 + j * 16 + q4;
             if (row >= M || col >= N) continue;
             f32x4 v = tot[i][j] + sm[i][j];
             if (bias) { v[0] += bias[col]; if (col + 1 < N) v[1] += bias[col + 1]; if (col + 2 < N) v[2] += bias[col + 2]; if (col + 3 < N) v[3] += bias[col + 3]; }
@@ -269,8 +258,8 @@ __global__ __launch_bounds__(256, 1) void gemm_f32x6_kernel(const unsigned short
 }
 
 int init_gemm_x6_attributes() {
-    MDD_HIP_CHECK(hipFuncSetAttribute((const void *)gemm_f32x6_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * X6_STAGE));
-    MDD_HIP_CHECK(hipFuncSetAttribute((const void *)gemm_f32x6_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * X6_STAGE));
+    MDD_HIP_CHECK(hipFuncSetAttribute((const void *)gemm_f32x6_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, X6_NS * X6_STAGE));
+    MDD_HIP_CHECK(hipFuncSetAttribute((const void *)gemm_f32x6_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, X6_NS * X6_STAGE));
     return MDD_OK;
 }
 
@@ -283,8 +272,8 @@ int launch_gemm_f32x6(const unsigned short *A3, size_t a_plane, const unsigned s
     }
     const int tn = (N + X6_BN - 1) / X6_BN;
     const dim3 grid(((M + X6_BM - 1) / X6_BM) * tn);
-    if (stamps) hipLaunchKernelGGL(gemm_f32x6_kernel<true>, grid, dim3(256), 2 * X6_STAGE, st, A3, W3, a_plane, w_plane, bias, C, M, N, K, ldc, tn, stamps);
-    else hipLaunchKernelGGL(gemm_f32x6_kernel<false>, grid, dim3(256), 2 * X6_STAGE, st, A3, W3, a_plane, w_plane, bias, C, M, N, K, ldc, tn, (long long *)nullptr);
+    if (stamps) hipLaunchKernelGGL(gemm_f32x6_kernel<true>, grid, dim3(256), X6_NS * X6_STAGE, st, A3, W3, a_plane, w_plane, bias, C, M, N, K, ldc, tn, stamps);
+    else hipLaunchKernelGGL(gemm_f32x6_kernel<false>, grid, dim3(256), X6_NS * X6_STAGE, st, A3, W3, a_plane, w_plane, bias, C, M, N, K, ldc, tn, (long long *)nullptr);
     MDD_LAUNCH_CHECK();
     return MDD_OK;
 }
@@ -391,8 +380,8 @@ extern "C" int mdd_diag_gemm_time(int mode, int M, int N, int K, int reps, float
                 double sum[4] = {0, 0, 0, 0}; size_t cnt = 0;
                 for (size_t w_ = 0; w_ < 1024 * 4; w_++) if (h[w_ * 4 + 0] > 0) { for (int i = 0; i < 4; i++) sum[i] += (double)h[w_ * 4 + i]; cnt++; }
                 const double d = (double)cnt * (K / 32);
-                if (cnt) printf("  f32x6 stamps, cycles per K-tile and wave: MFMA stream %.0f (ideal %d), LDS-DMA wait %.0f, barrier %.0f\n",
-                                (sum[0] + sum[3]) / d, X6_RT * 4 * 6 * 16, sum[1] / d, sum[2] / d);
+                if (cnt) printf("  f32x6 stamps, cycles per K-tile and wave: MFMA stream %.0f (ideal %d), memory wait %.0f, barrier %.0f\n",
+                                sum[0] / d, X6_RT * 8 * 6 * 16, sum[1] / d, sum[2] / d);
                 fflush(stdout);
             }
             (void)hipFree(sd);

@@ -19,14 +19,14 @@ class HipModel(object):
                              channels=geom.channels, emb_rows=geom.emb_rows, emb_dim=geom.emb_dim, bn_eps=1e-5)
         _lib.check(_lib.lib().mdd_create(C.byref(cfg), device, C.byref(self.handle)))
         if precision is not None:      # 'f32' (exact fp32 MFMA: the default) or 'bf16x3' (split-bf16, the flagged variant)
-            _lib.check(_lib.lib().mdd_set_precision(self.handle, {'f32': 0, 'bf16x3': 1}[precision]))
+            _lib.check(_lib.lib().mdd_set_precision(self.handle, {'f32': 0, 'bf16x3': 1, 'f32x6': 2}[precision]))
         self.load_state_dict(state_dict)
         if taps:
             _lib.check(_lib.lib().mdd_enable_taps(self.handle, 1))
 
     @property
     def precision(self):
-        return {0: 'f32', 1: 'bf16x3'}[_lib.lib().mdd_get_precision(self.handle)]
+        return {0: 'f32', 1: 'bf16x3', 2: 'f32x6'}[_lib.lib().mdd_get_precision(self.handle)]
 
     def load_state_dict(self, state_dict):
         L = _lib.lib()

@@ -34,7 +34,7 @@ def _bilstm(x, sd, prefix, bias, batch_first=False):
     return out
 
 
-def forward(sd_np, x, x1, dtype=torch.float32):
+def forward(sd_np, x, x1, dtype=torch.float32, taps=None):
     """Eval-mode CTC_Model.forward on CPU tensors.  sd_np: dict key -> numpy; x [B,T,F]; x1 [B,L] long.  dtype=torch.float64 runs the
     same graph in double (the yardstick for "whose fp32 evaluation is closer": tests/test_gpu_parity.py)."""
     sd = {k: (torch.as_tensor(v).to(dtype) if np.asarray(v).dtype.kind == "f" else torch.as_tensor(v)) for k, v in sd_np.items()}
@@ -47,15 +47,22 @@ def forward(sd_np, x, x1, dtype=torch.float32):
             a = F.relu(_bn(a, sd, "conv.%d.batch_norm" % n))
         B, C, T, W = a.shape
         seq = a.transpose(1, 2).contiguous().view(B, T, C * W).transpose(0, 1).contiguous()
+        if taps is not None:
+            taps["conv1"] = seq.numpy().copy()
         n = 0
         while "rnns.%d.rnn.weight_ih_l0" % n in sd:
             if n > 0:
                 seq = _bn(seq.transpose(-1, -2), sd, "rnns.%d.batch_norm" % n).transpose(-1, -2)
             seq = _bilstm(seq, sd, "rnns.%d.rnn" % n, bias=False)
+            if taps is not None:
+                taps["rnn%d" % n] = seq.numpy().copy()
             n += 1
         X = seq.transpose(0, 1)
         val = _bilstm(F.embedding(x1, sd["embeds.weight"]), sd, "lstm_embeds", bias=True, batch_first=True)
         key = F.linear(val, sd["score.weight"])
+        if taps is not None:
+            taps["text"] = val.transpose(0, 1).numpy().copy()      # [L, B, 2H], the library's tap layout
+            taps["key"] = key.transpose(0, 1).numpy().copy()
         attn = torch.softmax(torch.bmm(X, key.transpose(1, 2)), dim=-1)
         cat = torch.cat((X, torch.bmm(attn, val)), -1).transpose(0, 1).contiguous()
         Tp = cat.shape[0]

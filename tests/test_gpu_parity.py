@@ -42,7 +42,7 @@ def test_forward_tiny_every_stage():
     np.testing.assert_allclose(logp, oracle.forward(sd, g["x"], g["x1"]), rtol=0, atol=TOL)
 
 
-@pytest.mark.parametrize("precision", ["f32", "bf16x3"])
+@pytest.mark.parametrize("precision", ["f32", "f32x6", "bf16x3"])
 @pytest.mark.parametrize("idx", [0, 1, 2])
 def test_forward_reference_geometry_golden(idx, precision):
     meta = jload("g2_ref.json")[idx]
@@ -98,7 +98,7 @@ def test_dropin_class_matches_golden_and_reference_api():
         model(torch.from_numpy(x), bad)
 
 
-@pytest.mark.parametrize("precision", ["f32", "bf16x3"])
+@pytest.mark.parametrize("precision", ["f32", "f32x6", "bf16x3"])
 def test_forward_full_size_properties(precision):
     """BASELINE config size (B=64, 10 s): rows are distributions; an utterance's posteriors do not depend on
     the other utterances of the batch (eval mode has no cross-batch op), bit for bit; and a 2-utterance
@@ -238,7 +238,7 @@ def test_persistent_lstm_equals_step_kernels_bitwise(monkeypatch):
 
 # ---------------------------------------------------------------------------- edge cases
 @pytest.mark.parametrize("B,T,L", [(1, 2, 1), (1, 8, 3), (17, 8, 5), (33, 6, 2)])
-@pytest.mark.parametrize("precision", ["f32", "bf16x3"])
+@pytest.mark.parametrize("precision", ["f32", "f32x6", "bf16x3"])
 def test_forward_edge_shapes_against_oracle(B, T, L, precision):
     """Smallest legal input (one output frame, one canonical phoneme), batch sizes that are not multiples of the
     MFMA tile, ragged padding -- reference geometry, against the CPU oracle."""
@@ -551,7 +551,7 @@ def test_wav_to_diagnosis_end_to_end():
         assert rep["score"] == meta["records"][0]["beam_chain"]["score"]
 
 
-@pytest.mark.parametrize("precision", ["f32", "bf16x3"])
+@pytest.mark.parametrize("precision", ["f32", "f32x6", "bf16x3"])
 def test_vocabulary_single_all_words(precision):
     """BASELINE configs[0] over ALL 20 words of egs/vocabulary/single (G12, made by the reference's own chain): N.txt -> the offline
     lexicon (dict/phonetic_dict.py: CMU dictionary lookup + the stress post-processing of AA/infer.py:543-548) -> canonical ids,
@@ -627,7 +627,7 @@ def test_vocabulary_single_all_words(precision):
     assert chained == 18 and same_b == 18
 
 
-@pytest.mark.parametrize("precision", ["f32", "bf16x3"])
+@pytest.mark.parametrize("precision", ["f32", "f32x6", "bf16x3"])
 @pytest.mark.parametrize("idx", [0, 1, 2])
 def test_benchmarked_length_golden_and_chain(idx, precision):
     """G9 (made by the reference's own Python): log-probs at the benchmarked length T'=250 (ragged lengths, ragged L,
@@ -700,19 +700,21 @@ def test_error_against_fp64_beside_aten_fp32():
     ref64 = ref_port.forward(sd, x, x1, dtype=torch.float64).numpy()
     aten32 = ref_port.forward(sd, x, x1).numpy().astype(np.float64)
     got = {p: _hip().HipModel(geom, sd, precision=p).forward(_cuda(x), _cuda(x1), sync_errors=True).cpu().numpy().astype(np.float64)
-           for p in ("f32", "bf16x3")}
+           for p in ("f32", "bf16x3", "f32x6")}
     lens = (torch.from_numpy(frac) * 250).long().numpy()
     live = np.zeros(ref64.shape[:2], dtype=bool)
     for b, n in enumerate(lens):
         live[:n, b] = True                                       # frames the decoders read (padded frames are computed too, by both sides)
     stats = {}
-    for name, v in (("aten_f32", aten32), ("hip_f32", got["f32"]), ("hip_bf16x3", got["bf16x3"])):
+    for name, v in (("aten_f32", aten32), ("hip_f32", got["f32"]), ("hip_f32x6", got["f32x6"]), ("hip_bf16x3", got["bf16x3"])):
         d = np.abs(v - ref64)
         stats[name] = (float(d.max()), float(d.mean()), float(d[live].max()))
         record_margin("fp64_distance_%s_max" % name, stats[name][0], TOL)
         record_margin("fp64_distance_%s_mean" % name, stats[name][1])
     print("distance to the float64 evaluation, B=64 x T'=250: " + "; ".join("%s max %.2e mean %.2e" % (k, v[0], v[1]) for k, v in stats.items()))
     assert stats["hip_f32"][0] <= 2.0 * stats["aten_f32"][0] and stats["hip_f32"][1] <= 2.0 * stats["aten_f32"][1]
+    # f32x6 (three bf16 planes per operand in the input projections): it must be AT LEAST as close to float64 as ATen's fp32 is
+    assert stats["hip_f32x6"][1] <= stats["aten_f32"][1] and stats["hip_f32x6"][0] <= 1.25 * stats["aten_f32"][0], stats
     assert stats["hip_bf16x3"][0] < TOL
 
 
