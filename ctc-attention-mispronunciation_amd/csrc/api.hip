@@ -62,7 +62,7 @@ struct mdd_model {
     float *w_score = nullptr, *fscale = nullptr, *fshift = nullptr, *w_fc = nullptr, *w_fcp = nullptr;
     std::vector<mdd::SplitPtr> wih_s, whh_s;                // split-bf16 copies of the GEMM / recurrent weights
     std::vector<unsigned short *> wih_3;                    // three-plane (f32x6) copies of the input-projection weights, K-tile-major
-    unsigned short *t_wih_3 = nullptr;
+    unsigned short *t_wih_3 = nullptr, *w_conv1_3 = nullptr; // (conv1 weights [co][kh][kw][ci] as three row-major planes)
     mdd::SplitPtr t_whh_s{nullptr, nullptr};
     mdd::SplitPtr t_wih_s{nullptr, nullptr}, w_score_s{nullptr, nullptr}, w_conv1_s{nullptr, nullptr};
     std::vector<void *> owned;  // every hipMalloc'd weight pointer
@@ -86,7 +86,7 @@ struct mdd_model {
     int n_cu = 0;
     unsigned int *sync_words = nullptr;
     bool lstm_x3 = false;   // MDD_LSTM=x3: LDS-tiled split-bf16 step kernel (measured slower than the packed fp32 step; kept for study)
-    bool conv_fused() const { return x3() && cfg.feat == 243 && cfg.channels == 32; }
+    bool conv_fused() const { return (x3() || x6()) && cfg.feat == 243 && cfg.channels == 32; }
     bool packed_h() const { return cfg.hidden == 384 || cfg.hidden == 256; }
     // one persistent launch per BiLSTM layer: the split-bf16 teams (lstm.hip) in mode 1, the exact-fp32 teams (lstm_f32.hip) in mode 0
     bool persist(int B) const { return lstm_persist && !lstm_x3 && packed_h() && B <= granule_max_b && (x3() || lstm_persist_f32); }
@@ -226,6 +226,9 @@ static int run_stage(mdd_model *m, int si, const float *x, int B, int T, const i
     if (si == 0 && m->conv_fused()) {   // conv0 recomputed per output row (x1.5) + conv1 as implicit GEMM, one kernel
         info->name = "conv_fused";
         info->flops = 2.0 * 9 * c.channels * (double)B * Tp * m->W2() * (c.channels + 6.0);
+        if (m->x6())   // fp32-grade form: three K-tile-major planes straight into the projection GEMM's operand buffer
+            return launch_conv_fused3(x, m->w_conv0, m->sc0, m->sh0, m->w_conv1_3, m->sc1, m->sh1, reinterpret_cast<unsigned short *>(m->p3.p),
+                                      m->taps ? m->seq0.p : nullptr, B, T, m->raw_T, st);
         return launch_conv_fused(x, m->w_conv0, m->sc0, m->sh0, m->w_conv1_s, m->sc1, m->sh1, split_view(m->seq0_s, rows * m->rnn_in()),
                                  nullptr, B, T, m->raw_T, st);
     }
@@ -249,7 +252,8 @@ static int run_stage(mdd_model *m, int si, const float *x, int B, int T, const i
             const float *in = n == 0 ? m->seq0.p : m->act[(n - 1) & 1].p;
             if (m->x6()) {   // fp32-grade arithmetic at 6/16 of the fp32 MFMA's cost (gemm_bf16x6.hip)
                 unsigned short *p3 = reinterpret_cast<unsigned short *>(m->p3.p);
-                if (int rc = launch_split3(in, Tp * B, K, K, p3, st)) return rc;
+                if (!(n == 0 && m->conv_fused()))      // (layer 0: the fused front-end has written the planes already)
+                    if (int rc = launch_split3(in, Tp * B, K, K, p3, st)) return rc;
                 return launch_gemm_f32x6(p3, (size_t)Tp * B * K, m->wih_3[n], (size_t)G2 * K, nullptr, m->gx.p, Tp * B, G2, K, G2, st);
             }
             return launch_gemm_nt(in, m->wih[n], nullptr, m->gx.p, Tp * B, G2, K, K, K, G2, 1, 0, 0, 0, st);
@@ -476,6 +480,19 @@ extern "C" int mdd_finalize_weights(mdd_model *m) {
             for (int ci = 0; ci < ch; ci++)
                 for (int k = 0; k < 9; k++) tmp[((size_t)co * 9 + k) * ch + ci] = (*w1)[((size_t)co * ch + ci) * 9 + k];
         if ((rc = upload_split(m, tmp, &m->w_conv1_s))) return rc;
+        {   // the same matrix as three planes (hi | mid | lo, each [co][288] row-major) for the fp32-grade fused front-end
+            const size_t n = tmp.size();
+            std::vector<unsigned short> buf(3 * n);
+            for (size_t i = 0; i < n; i++) {
+                buf[i] = host_bf16(tmp[i]);
+                const float r1 = tmp[i] - host_bf16_f32(buf[i]);
+                buf[n + i] = host_bf16(r1);
+                buf[2 * n + i] = host_bf16(r1 - host_bf16_f32(buf[n + i]));
+            }
+            MDD_HIP_CHECK(hipMalloc((void **)&m->w_conv1_3, 3 * n * sizeof(unsigned short)));
+            m->owned.push_back(m->w_conv1_3);
+            MDD_HIP_CHECK(hipMemcpy(m->w_conv1_3, buf.data(), 3 * n * sizeof(unsigned short), hipMemcpyHostToDevice));
+        }
     }
     for (int n = 0; n < c.layers; n++) {
         char base[64];

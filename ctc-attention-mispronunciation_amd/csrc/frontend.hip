@@ -172,7 +172,13 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int CF_XLD = 248, CF_COLB = 80, CF_NCOL = 124, CF_YPLANE = 3 * CF_NCOL * CF_COLB;   // 29760 B
 
-__global__ __launch_bounds__(256, 2) void conv_fused_kernel(const float *__restrict__ x, const float *__restrict__ w0,
+// NP = 2: the split-bf16 x3 form (operands as hi + lo, products hi.lo + lo.hi + hi.hi; output: two row-major planes).
+// NP = 3: the fp32-grade form of the f32x6 mode (gemm_bf16x6.hip): every operand as hi + mid + lo = all 24 significand bits, the six
+// products down to 2^-24 of a product, smallest first; the contractions here are short (9 taps; 288 / 2 per wave), so one accumulator
+// does.  Output: three planes in the K-TILE-MAJOR order the f32x6 projection GEMM streams (plane[kt][row][32], kt = column / 32), i.e.
+// the conv output never exists as fp32 and needs no split pass.  w1l holds the mid plane followed by the lo plane in that case.
+template <int NP>
+__global__ __launch_bounds__(256, NP == 2 ? 2 : 1) void conv_fused_kernel(const float *__restrict__ x, const float *__restrict__ w0,
                                                             const float *__restrict__ sc0, const float *__restrict__ sh0,
                                                             const unsigned short *__restrict__ w1h, const unsigned short *__restrict__ w1l,
                                                             const float *__restrict__ sc1, const float *__restrict__ sh1,
@@ -183,36 +189,43 @@ __global__ __launch_bounds__(256, 2) void conv_fused_kernel(const float *__restr
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float *xs = reinterpret_cast<float *>(smem);                                   // [5][CF_XLD]
     unsigned char *yh = smem + 5 * CF_XLD * 4, *yl = yh + CF_YPLANE;               // conv0 tile, hi / lo
-    float *red = reinterpret_cast<float *>(yl + CF_YPLANE);                        // [2][1024]
-    unsigned short *oh = reinterpret_cast<unsigned short *>(red + 2048), *ol = oh + ROW;
+    unsigned char *ym = yl + CF_YPLANE;                                            // (NP = 3) mid
+    float *red = reinterpret_cast<float *>(yl + (NP - 1) * CF_YPLANE);             // [2][1024]
+    unsigned short *oh = reinterpret_cast<unsigned short *>(red + 2048), *ol = oh + ROW, *om = ol + ROW;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int mt = wave & 1, kh2 = wave >> 1;                                      // M tile, K half of this wave
     const int li = lane & 31, half = lane >> 5;
     const int Tp = T / 2;
 
     // resident B fragments: W1[co = li][k], this wave's 9 k-steps of 16
-    bf16x8 bwh[9], bwl[9];
+    bf16x8 bwh[9], bwl[9], bwm[NP == 3 ? 9 : 1];
 #pragma unroll
     for (int i = 0; i < 9; i++) {
         const int kb = kh2 * 9 + i;
         bwh[i] = *reinterpret_cast<const bf16x8 *>(w1h + (size_t)li * 288 + kb * 16 + half * 8);
-        bwl[i] = *reinterpret_cast<const bf16x8 *>(w1l + (size_t)li * 288 + kb * 16 + half * 8);
+        if (NP == 3) {
+            bwm[i] = *reinterpret_cast<const bf16x8 *>(w1l + (size_t)li * 288 + kb * 16 + half * 8);
+            bwl[i] = *reinterpret_cast<const bf16x8 *>(w1l + (size_t)CH * 288 + (size_t)li * 288 + kb * 16 + half * 8);
+        } else bwl[i] = *reinterpret_cast<const bf16x8 *>(w1l + (size_t)li * 288 + kb * 16 + half * 8);
     }
     // conv0 weights as resident A fragments: lane (channel li, k-slice half): taps half*8 .. half*8+7 (taps >= 9 are zero)
-    bf16x8 w0h, w0l;
+    bf16x8 w0h, w0l, w0m;
 #pragma unroll
     for (int j = 0; j < 8; j++) {
         const int tap = half * 8 + j;
         const float wv = tap < 9 ? w0[li * 9 + tap] : 0.f;
-        w0h[j] = (__bf16)wv; w0l[j] = (__bf16)(wv - (float)w0h[j]);
+        w0h[j] = (__bf16)wv;
+        const float r1 = wv - (float)w0h[j];
+        if (NP == 3) { w0m[j] = (__bf16)r1; w0l[j] = (__bf16)(r1 - (float)w0m[j]); }
+        else { w0l[j] = (__bf16)r1; w0m[j] = (__bf16)0.f; }
     }
     float c0s[16], c0h[16];      // folded BN of the 16 channels this lane receives in D: reg q -> channel (q&3) + 8*(q>>2) + 4*half
 #pragma unroll
     for (int q = 0; q < 16; q++) { const int ch = (q & 3) + 8 * (q >> 2) + 4 * half; c0s[q] = sc0[ch]; c0h[q] = sh0[ch]; }
     // zero the left pad column of the conv0 tile once (wcol = -1)
-    for (int i = tid; i < 3 * 2 * CF_COLB / 4; i += 256) {
-        const int r = i / (2 * CF_COLB / 4), rem = i - r * (2 * CF_COLB / 4);
-        reinterpret_cast<unsigned int *>((rem < CF_COLB / 4 ? yh : yl) + r * CF_NCOL * CF_COLB)[rem % (CF_COLB / 4)] = 0u;
+    for (int i = tid; i < 3 * NP * CF_COLB / 4; i += 256) {
+        const int r = i / (NP * CF_COLB / 4), rem = i - r * (NP * CF_COLB / 4), pl = rem / (CF_COLB / 4);
+        reinterpret_cast<unsigned int *>((pl == 0 ? yh : pl == 1 ? yl : ym) + r * CF_NCOL * CF_COLB)[rem % (CF_COLB / 4)] = 0u;
     }
 
     // x rows 2tp-2 .. 2tp+2, columns -1 .. 243 (zero outside) of one output row: 5*248 elements, 5 per thread.  The next
@@ -268,30 +281,50 @@ __global__ __launch_bounds__(256, 2) void conv_fused_kernel(const float *__restr
                 const int tap = half * 8 + j, kh = tap / 3, kw = tap - kh * 3;           // taps 9..15 are padding
                 v[j] = (tap < 9) ? xs[(r + kh) * CF_XLD + 2 * wc + kw] : 0.f;
             }
-            bf16x8 bh, bl;
+            bf16x8 bh, bl, bm;
 #pragma unroll
-            for (int j = 0; j < 8; j++) { bh[j] = (__bf16)v[j]; bl[j] = (__bf16)(v[j] - (float)bh[j]); }
+            for (int j = 0; j < 8; j++) {
+                bh[j] = (__bf16)v[j];
+                const float r1 = v[j] - (float)bh[j];
+                if (NP == 3) { bm[j] = (__bf16)r1; bl[j] = (__bf16)(r1 - (float)bm[j]); }
+                else bl[j] = (__bf16)r1;
+            }
             f32x16 d;
 #pragma unroll
             for (int q = 0; q < 16; q++) d[q] = 0.f;
-            d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0h, bl, d, 0, 0, 0);
-            d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0l, bh, d, 0, 0, 0);
+            if (NP == 3) {
+                d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0m, bm, d, 0, 0, 0);
+                d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0h, bl, d, 0, 0, 0);
+                d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0l, bh, d, 0, 0, 0);
+                d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0h, bm, d, 0, 0, 0);
+                d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0m, bh, d, 0, 0, 0);
+            } else {
+                d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0h, bl, d, 0, 0, 0);
+                d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0l, bh, d, 0, 0, 0);
+            }
             d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0h, bh, d, 0, 0, 0);
             if (p < 3 * W1) {
                 unsigned char *dh = yh + (rs * CF_NCOL + wc + 1) * CF_COLB, *dl = yl + (rs * CF_NCOL + wc + 1) * CF_COLB;
+                unsigned char *dm = ym + (rs * CF_NCOL + wc + 1) * CF_COLB;
 #pragma unroll
                 for (int g = 0; g < 4; g++) {      // registers 4g..4g+3 = channels 8g + 4*half + 0..3
-                    unsigned short hb[4], lb[4];
+                    unsigned short hb[4], lb[4], mb[4];
 #pragma unroll
                     for (int e = 0; e < 4; e++) {
                         float a = d[4 * g + e] * c0s[4 * g + e] + c0h[4 * g + e];
                         a = (rowok && a > 0.f) ? a : 0.f;
-                        __bf16 h = (__bf16)a, l = (__bf16)(a - (float)h);
-                        hb[e] = *reinterpret_cast<unsigned short *>(&h); lb[e] = *reinterpret_cast<unsigned short *>(&l);
+                        __bf16 h = (__bf16)a;
+                        const float r1 = a - (float)h;
+                        hb[e] = *reinterpret_cast<unsigned short *>(&h);
+                        if (NP == 3) {
+                            __bf16 mm_ = (__bf16)r1, l = (__bf16)(r1 - (float)mm_);
+                            mb[e] = *reinterpret_cast<unsigned short *>(&mm_); lb[e] = *reinterpret_cast<unsigned short *>(&l);
+                        } else { __bf16 l = (__bf16)r1; lb[e] = *reinterpret_cast<unsigned short *>(&l); }
                     }
                     const int cb = (8 * g + 4 * half) * 2;
                     *reinterpret_cast<uint2 *>(dh + cb) = make_uint2(hb[0] | ((unsigned)hb[1] << 16), hb[2] | ((unsigned)hb[3] << 16));
                     *reinterpret_cast<uint2 *>(dl + cb) = make_uint2(lb[0] | ((unsigned)lb[1] << 16), lb[2] | ((unsigned)lb[3] << 16));
+                    if (NP == 3) *reinterpret_cast<uint2 *>(dm + cb) = make_uint2(mb[0] | ((unsigned)mb[1] << 16), mb[2] | ((unsigned)mb[3] << 16));
                 }
             }
         }
@@ -308,8 +341,17 @@ __global__ __launch_bounds__(256, 2) void conv_fused_kernel(const float *__restr
             const int off = (khs * CF_NCOL + 2 * m + kw) * CF_COLB + ((kb & 1) * 16 + half * 8) * 2;   // col index = (2m+kw-1)+1
             const bf16x8 ah = *reinterpret_cast<const bf16x8 *>(yh + off);
             const bf16x8 al = *reinterpret_cast<const bf16x8 *>(yl + off);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bwl[i], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bwh[i], acc, 0, 0, 0);
+            if (NP == 3) {
+                const bf16x8 am = *reinterpret_cast<const bf16x8 *>(ym + off);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bwm[i], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bwl[i], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bwh[i], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bwm[i], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bwh[i], acc, 0, 0, 0);
+            } else {
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bwl[i], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bwh[i], acc, 0, 0, 0);
+            }
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bwh[i], acc, 0, 0, 0);
         }
         // ---- reduce the two K halves, BN + ReLU, transpose to the output row through LDS
@@ -326,15 +368,32 @@ __global__ __launch_bounds__(256, 2) void conv_fused_kernel(const float *__restr
                 if (wo < W2) {
                     float v = (acc[r] + red[mt * 1024 + r * 64 + lane]) * s1 + h1;
                     v = v > 0.f ? v : 0.f;
-                    __bf16 hb = (__bf16)v, lb = (__bf16)(v - (float)hb);
+                    __bf16 hb = (__bf16)v;
+                    const float r1 = v - (float)hb;
                     oh[li * W2 + wo] = *reinterpret_cast<unsigned short *>(&hb);
-                    ol[li * W2 + wo] = *reinterpret_cast<unsigned short *>(&lb);
+                    if (NP == 3) {
+                        __bf16 mb = (__bf16)r1, lb = (__bf16)(r1 - (float)mb);
+                        om[li * W2 + wo] = *reinterpret_cast<unsigned short *>(&mb);
+                        ol[li * W2 + wo] = *reinterpret_cast<unsigned short *>(&lb);
+                    } else { __bf16 lb = (__bf16)r1; ol[li * W2 + wo] = *reinterpret_cast<unsigned short *>(&lb); }
                 }
             }
         }
         __syncthreads();
-        // ---- coalesced row store: 1952 bf16 = 244 x 16 B per plane
-        {
+        // ---- row store.  NP = 3: 16-byte chunk q of a plane row = columns 8q .. 8q+7 = K-tile q / 4, offset (q % 4) * 8 of the tile-major
+        // plane (out_hi = hi plane; mid and lo follow at plane strides of rows_total * 1952 elements, passed in out_lo as the mid plane)
+        if (NP == 3) {
+            const size_t mrows = (size_t)Tp * B;
+            if (tid < 244) {
+                const size_t dst = (((size_t)(tid >> 2) * mrows + rowid) * 32 + (tid & 3) * 8);
+                *reinterpret_cast<u32x4 *>(out_hi + dst) = *reinterpret_cast<const u32x4 *>(oh + tid * 8);
+                *reinterpret_cast<u32x4 *>(out_lo + dst) = *reinterpret_cast<const u32x4 *>(om + tid * 8);
+                *reinterpret_cast<u32x4 *>(out_lo + mrows * ROW + dst) = *reinterpret_cast<const u32x4 *>(ol + tid * 8);
+            }
+            if (out_f32)
+                for (int i = tid; i < ROW; i += 256)
+                    out_f32[(size_t)rowid * ROW + i] = (__uint_as_float((unsigned)oh[i] << 16) + __uint_as_float((unsigned)om[i] << 16)) + __uint_as_float((unsigned)ol[i] << 16);
+        } else {
             const size_t base = (size_t)rowid * ROW;
             if (tid < 244) *reinterpret_cast<u32x4 *>(out_hi + base + tid * 8) = *reinterpret_cast<const u32x4 *>(oh + tid * 8);
             else if (tid - 244 < 12) {   // 12 threads left in this pass: start the lo plane
@@ -352,7 +411,7 @@ __global__ __launch_bounds__(256, 2) void conv_fused_kernel(const float *__restr
     }
 }
 
-size_t conv_fused_smem() { return 5 * CF_XLD * 4 + 2 * (size_t)CF_YPLANE + 2048 * 4 + 2 * 1952 * 2; }
+size_t conv_fused_smem(int np) { return 5 * CF_XLD * 4 + (size_t)np * CF_YPLANE + 2048 * 4 + (size_t)np * 1952 * 2; }
 
 int launch_conv_fused(const float *x, const float *w0, const float *sc0, const float *sh0, SplitPtr w1, const float *sc1,
                       const float *sh1, SplitPtr out, float *out_f32, int B, int T, int Traw, hipStream_t st) {
@@ -363,14 +422,32 @@ int launch_conv_fused(const float *x, const float *w0, const float *sc0, const f
     S = S < 1 ? 1 : (S > Tp ? Tp : S);
     const int seg = (Tp + S - 1) / S;
     S = (Tp + seg - 1) / seg;                                                      // no empty segments
-    hipLaunchKernelGGL(conv_fused_kernel, dim3(B * S), dim3(256), conv_fused_smem(), st, x, w0, sc0, sh0, w1.hi, w1.lo, sc1, sh1,
+    hipLaunchKernelGGL(conv_fused_kernel<2>, dim3(B * S), dim3(256), conv_fused_smem(2), st, x, w0, sc0, sh0, w1.hi, w1.lo, sc1, sh1,
                        out.hi, out.lo, out_f32, B, T, Traw, S, seg);
     MDD_LAUNCH_CHECK();
     return MDD_OK;
 }
 
+// f32x6 form: w1_3 = conv1 weights [co][kh][kw][ci] as three consecutive row-major planes (hi | mid | lo, 32 * 288 elements each);
+// out3 = three consecutive K-tile-major planes of (T/2 * B) x 1952 elements (the A operand of launch_gemm_f32x6)
+int launch_conv_fused3(const float *x, const float *w0, const float *sc0, const float *sh0, const unsigned short *w1_3, const float *sc1,
+                       const float *sh1, unsigned short *out3, float *out_f32, int B, int T, int Traw, hipStream_t st) {
+    const int Tp = T / 2;
+    if (Tp <= 0 || B <= 0) return MDD_OK;
+    int S = (512 + B - 1) / B;                                                     // one workgroup per CU (114 KB of LDS): two rounds of 256
+    S = S < 1 ? 1 : (S > Tp ? Tp : S);
+    const int seg = (Tp + S - 1) / S;
+    S = (Tp + seg - 1) / seg;
+    const size_t plane = (size_t)Tp * B * 1952;
+    hipLaunchKernelGGL(conv_fused_kernel<3>, dim3(B * S), dim3(256), conv_fused_smem(3), st, x, w0, sc0, sh0, w1_3, w1_3 + 32 * 288, sc1, sh1,
+                       out3, out3 + plane, out_f32, B, T, Traw, S, seg);
+    MDD_LAUNCH_CHECK();
+    return MDD_OK;
+}
+
 int init_conv_attributes() {
-    MDD_HIP_CHECK(hipFuncSetAttribute((const void *)conv_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+    MDD_HIP_CHECK(hipFuncSetAttribute((const void *)conv_fused_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+    MDD_HIP_CHECK(hipFuncSetAttribute((const void *)conv_fused_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
     return MDD_OK;
 }
 

@@ -64,6 +64,8 @@ int launch_conv1(const float *y0, const float *w_t, const float *scale, const fl
 // (w1: conv1 weights as [co][kh][kw][ci] hi/lo planes).  out_f32 optional (taps).
 int launch_conv_fused(const float *x, const float *w0, const float *sc0, const float *sh0, SplitPtr w1, const float *sc1,
                       const float *sh1, SplitPtr out, float *out_f32, int B, int T, int Traw, hipStream_t st);
+int launch_conv_fused3(const float *x, const float *w0, const float *sc0, const float *sh0, const unsigned short *w1_3, const float *sc1,
+                       const float *sh1, unsigned short *out3, float *out_f32, int B, int T, int Traw, hipStream_t st);   // f32x6 form: three K-tile-major planes out
 int init_conv_attributes();
 
 struct LstmStepArgs {
