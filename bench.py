@@ -17,8 +17,11 @@ every batch padded to its own maximum, 8 such batches per fused pass, frames cou
 B=64 batch per pass: the latency-bound case), `bf16x3_mode` (the flagged split-bf16 arithmetic, narrower than the reference's:
 MDD_PRECISION=bf16x3), `greedy32_h256` (configs[1]) and `train32_f32` / `train32_bf16x3` (configs[4]'s per-GPU shard: a full training
 step in exact fp32 and in the flagged split-bf16 variant; `--workload train32 [--train-precision bf16x3]` prints that line on its
-own, with the stage split).  The headline itself is REFERENCE-WIDTH arithmetic: every contraction an exact fp32 MFMA, as the
-reference's ATen fp32 ops (AA/models/model_ctc.py:27-29,59-66,149-158).
+own, with the stage split).  The headline itself is REFERENCE-WIDTH arithmetic (the library's default mode "f32x6"): every operand with
+its full 24-bit significand and fp32 accumulation, as the reference's ATen fp32 ops (AA/models/model_ctc.py:27-29,59-66,149-158) --
+the large contractions as three bf16 planes per operand / six products on the bf16 matrix cores, the rest as exact fp32 MFMAs -- and the
+line carries, measured in the same run against a float64 evaluation, how far its log-probs and ATen-fp32's are from it (`accuracy`);
+`f32_mfma_mode` is the same path with every product an exact fp32 MFMA.
 
 N>1 (launched by torch.distributed.run, one rank per GPU): utterance batches shard across ranks (weak
 scaling: every rank decodes its own 64-utterance batch) and the posteriors of all shards are all-gathered
@@ -461,6 +464,11 @@ DTYPE_X3 = ("f32 results from split-bf16 arithmetic: every contraction of the mo
 DTYPE_F32 = ("f32 -- reference width: every contraction of the model (conv0/conv1, BiLSTM input projections, the recurrent W_hh.h products, "
              "text projection, score, attention scores, classifier) is an exact fp32 MFMA (v_mfma_f32_32x32x2_f32 / 16x16x4_f32, fp32 "
              "accumulate), gates / softmax fp32, beam scores f64 -- the arithmetic of the reference's ATen fp32 ops")
+DTYPE_X6 = ("f32 -- reference width (operands with all 24 significand bits, fp32 accumulate; see `accuracy`: closer to a float64 evaluation than "
+            "ATen's own fp32): the large time-batched contractions (conv0/conv1, BiLSTM and text input projections) run on the bf16 matrix cores "
+            "as f32x6 = each fp32 operand as three bf16 planes hi+mid+lo (exact), the six cross products down to 2^-24, hi.hi in its own "
+            "accumulator; the recurrent W_hh.h products, score / attention / classifier are exact fp32 MFMAs; gates / softmax fp32, beam "
+            "scores f64")
 
 
 def variant(ctx, args, name, **kw):
@@ -643,6 +651,7 @@ def main():
 
     # ---- CPU baseline: the torch-CPU + Python-beam port of the reference path on a bounded sample
     cpu = None
+    accuracy = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.ragged:
         from oracle import ref_port
         from ctc_attention_mispronunciation_amd.utils.data_loader import stack_features
@@ -654,6 +663,14 @@ def main():
         t1 = time.perf_counter()
         lp_cpu = ref_port.forward(job.sd, xs, job.x1_np[:sb])
         t_fwd = time.perf_counter() - t1
+        # the same batch in float64 (the yardstick) beside ATen's fp32 and this run's posteriors: the accuracy the dtype string claims
+        lp64 = ref_port.forward(job.sd, xs, job.x1_np[:sb], dtype=torch.float64).numpy()
+        lp_gpu = job.model.forward_raw(job.raw[:sb], job.x1[:sb]).cpu().numpy().astype(np.float64)
+        d_at, d_gpu = np.abs(lp_cpu.numpy().astype(np.float64) - lp64), np.abs(lp_gpu - lp64)
+        accuracy = {"what": "distance of the log-probs [250, 64, 45] of one benchmarked batch to a float64 evaluation of the reference's graph (oracle/ref_port.py, CPU)",
+                    "aten_fp32_cpu": {"max": float(d_at.max()), "mean": float(d_at.mean())},
+                    "this_run": {"max": float(d_gpu.max()), "mean": float(d_gpu.mean()), "precision": job.model.precision},
+                    "tolerance_north_star": 1e-4}
         t1 = time.perf_counter()
         if job.decoder_kind == "beam":
             ref_port.beam(lp_cpu, [Tp] * sb, job.i2c, job.decoder.lm, BEAM_W, 0.0)
@@ -673,9 +690,8 @@ def main():
             "fuse1": variant(ctx, args, "fuse1", hidden=args.hidden, joint=True, fuse=1, ragged=False, precision=args.precision, steps=32, warmup=8),
             "ragged": variant(ctx, args, "ragged", hidden=args.hidden, joint=True, fuse=args.fuse, ragged=True, precision=args.precision, steps=64, warmup=16),
             "ragged_fuse1": variant(ctx, args, "ragged_fuse1", hidden=args.hidden, joint=True, fuse=1, ragged=True, precision=args.precision, steps=32, warmup=8),
-            ("f32_mode" if precision == "bf16x3" else "bf16x3_mode"):
-                variant(ctx, args, "other_mode", hidden=args.hidden, joint=True, fuse=args.fuse, ragged=False,
-                        precision="f32" if precision == "bf16x3" else "bf16x3", steps=64, warmup=16, roofline=True),
+            "f32_mfma_mode": variant(ctx, args, "f32_mfma_mode", hidden=args.hidden, joint=True, fuse=args.fuse, ragged=False, precision="f32", steps=32, warmup=8, roofline=True),
+            "bf16x3_mode": variant(ctx, args, "bf16x3_mode", hidden=args.hidden, joint=True, fuse=args.fuse, ragged=False, precision="bf16x3", steps=64, warmup=16, roofline=True),
             "greedy32_h256": variant(ctx, args, "greedy32_h256", hidden=256, joint=False, fuse=args.fuse, ragged=False, precision=args.precision,
                                      steps=64, warmup=16),
             "greedy32_h256_fuse1": variant(ctx, args, "greedy32_h256_fuse1", hidden=256, joint=False, fuse=1, ragged=False, precision=args.precision,
@@ -696,7 +712,7 @@ def main():
             "value": round(value, 1), "unit": "phoneme-frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
-            "dtype": DTYPE_X3 if precision == "bf16x3" else DTYPE_F32,
+            "dtype": {"bf16x3": DTYPE_X3, "f32": DTYPE_F32, "f32x6": DTYPE_X6}[precision],
             "data": "synthetic",
             "config": {"workload": ("joint CTC-attn decode: stack/skip + forward + beam(10) + align, B=64 x 10 s x 81-dim log-mel"
                                     if joint else "CTC-only greedy decode: stack/skip + forward + greedy + align, B=32 x 10 s"),
@@ -708,14 +724,14 @@ def main():
                        "decoder": decoder_kind, "beam": BEAM_W if decoder_kind == "beam" else 0, "lm_alpha": 0.0,
                        "parallelism": "utterance-batch shards x%d%s" % (world, (", all-gather of %s on its own stream" % gather_kind) if gather_kind else ""),
                        "posteriors": "random-weight model output (flat: every frame live, beam worst case)"},
-            "roofline": roof, "cpu_baseline": cpu, "variants": variants,
+            "roofline": roof, "cpu_baseline": cpu, "accuracy": accuracy, "variants": variants,
             "edit_distance_checksum": checksum,
         }
         if gather_ok is not None:
             line["gather_verified"] = gather_ok
             line["gather_timing"] = gather_timing
         if variants:
-            for k in ("fuse1", "ragged", "f32_mode", "bf16x3_mode", "greedy32_h256", "train32_f32", "train32_bf16x3"):
+            for k in ("fuse1", "ragged", "f32_mfma_mode", "bf16x3_mode", "greedy32_h256", "train32_f32", "train32_bf16x3"):
                 if k in variants:
                     line[k] = variants[k]["value"]
         print(json.dumps(line))

@@ -52,7 +52,8 @@ struct mdd_model {
     mdd_config cfg;
     int device = 0;
     bool finalized = false, taps = false, use_graph = true;
-    int precision = 0;   // 0 (default): reference width, exact fp32 MFMA everywhere; 1: split-bf16 x3 for every contraction (when the geometry allows; flagged variant)
+    int precision = 2;   // 2 (default): fp32-grade, the large contractions as f32x6 on the bf16 matrix cores (falls back to 0 when the geometry does not allow);
+                         // 0: exact fp32 MFMA everywhere; 1: split-bf16 x3 for every contraction (narrower than fp32: flagged variant)
     std::map<std::string, std::vector<float>> host;  // state_dict entries as loaded
     // device weights
     float *w_conv0 = nullptr, *sc0 = nullptr, *sh0 = nullptr;

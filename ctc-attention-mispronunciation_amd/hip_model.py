@@ -18,7 +18,7 @@ class HipModel(object):
         cfg = _lib.MddConfig(feat=geom.feat, hidden=geom.hidden, layers=geom.layers, num_class=geom.num_class,
                              channels=geom.channels, emb_rows=geom.emb_rows, emb_dim=geom.emb_dim, bn_eps=1e-5)
         _lib.check(_lib.lib().mdd_create(C.byref(cfg), device, C.byref(self.handle)))
-        if precision is not None:      # 'f32' (exact fp32 MFMA: the default) or 'bf16x3' (split-bf16, the flagged variant)
+        if precision is not None:      # 'f32x6' (fp32-grade on the bf16 matrix cores: the default), 'f32' (exact fp32 MFMA) or 'bf16x3' (flagged variant)
             _lib.check(_lib.lib().mdd_set_precision(self.handle, {'f32': 0, 'bf16x3': 1, 'f32x6': 2}[precision]))
         self.load_state_dict(state_dict)
         if taps:

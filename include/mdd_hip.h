@@ -67,17 +67,21 @@ int mdd_load_weight(mdd_model *m, const char *key, const float *data, const int6
  * repack LSTM gate rows for the step kernel.  Synchronises the device. */
 int mdd_finalize_weights(mdd_model *m);
 
-/* Arithmetic of the model's contractions.
- * 0 = reference width: every product is an exact fp32 MFMA (v_mfma_f32_32x32x2_f32 in the time-batched GEMMs,
- *     v_mfma_f32_16x16x4_f32 in the recurrent W_hh.h products and the convolutions), fp32 accumulate -- the arithmetic of
- *     the reference's ATen fp32 ops (AA/models/model_ctc.py:27-29,59-66,149-158).
- * 1 = split-bf16 "x3" on v_mfma_f32_16x16x32_bf16: each fp32 operand = bf16 hi + bf16 lo (~16 significand bits),
- *     products hi.lo + lo.hi + hi.hi, fp32 accumulate.  This covers EVERY contraction of the forward: conv0 / conv1, the
- *     BiLSTM input projections, the recurrent W_hh.h products (h is re-split every step), the text projection, `score`
- *     and the attention scores; cell state, gates, softmax and the classifier tail stay fp32.  Measured effect on the
- *     log-probs <= 1e-5 (tolerance 1e-4).  Narrower than the reference's arithmetic: a flagged variant.
- *     Mode 1 falls back to 0 when a contraction length is not a multiple of 32 or the hidden size is not 256 / 384.
- * Env MDD_PRECISION=f32 / bf16x3 selects the mode at mdd_create.  mdd_get_precision returns the mode actually in use. */
+/* Arithmetic of the model's contractions.  Modes 2 and 0 are reference width (the arithmetic of the reference's ATen fp32 ops,
+ * AA/models/model_ctc.py:27-29,59-66,149-158: every operand with its full 24-bit significand, fp32 accumulation); measured against a
+ * float64 evaluation both are CLOSER to it than ATen's own fp32 (tests/test_gpu_parity.py::test_error_against_fp64_beside_aten_fp32).
+ * 2 (default) = "f32x6": the large time-batched contractions -- conv0 / conv1 and the BiLSTM / text input projections -- on the bf16
+ *     matrix cores with every fp32 operand carried as THREE bf16 planes (hi + mid + lo = its 24 significand bits exactly) and the six
+ *     cross products down to 2^-24 of a product, fp32 accumulate, hi.hi in an accumulator of its own (gemm_bf16x6.hip: 6/16 of the cost
+ *     of the fp32 MFMA, which on gfx950 runs at the fp32 vector rate); everything else as mode 0.  Needs contraction lengths that are
+ *     multiples of 32 (falls back to 0 otherwise).
+ * 0 = every product an exact fp32 MFMA (v_mfma_f32_32x32x2_f32 in the time-batched GEMMs, v_mfma_f32_16x16x4_f32 in the recurrent
+ *     W_hh.h products, the attention tail and the convolutions).
+ * 1 = split-bf16 "x3" on v_mfma_f32_16x16x32_bf16: each fp32 operand = bf16 hi + bf16 lo (~16 significand bits), products hi.lo +
+ *     lo.hi + hi.hi, for EVERY contraction of the forward including the recurrent W_hh.h products (h is re-split every step); cell state,
+ *     gates, softmax and the classifier tail stay fp32.  Measured effect on the log-probs <= 1e-5 (tolerance 1e-4).  NARROWER than the
+ *     reference's arithmetic: a flagged variant.  Falls back to 0 when a contraction length is not a multiple of 32 or H is not 256 / 384.
+ * Env MDD_PRECISION=f32x6 / f32 / bf16x3 selects the mode at mdd_create.  mdd_get_precision returns the mode actually in use. */
 int mdd_set_precision(mdd_model *m, int32_t mode);
 int32_t mdd_get_precision(mdd_model *m);
 

@@ -1394,8 +1394,10 @@ def test_fused_batches_of_different_lengths_equal_their_own_runs(precision, lstm
     for lp, (b, T, L) in zip(alone, shapes):
         np.testing.assert_array_equal(fused[:T // 2, r:r + b], lp)
         r += b
+    # run to run: every DEFINED row (t < frames[b]; rows beyond are undefined by the interface and may depend on what the workspace held)
     again = m.forward_fused(_cuda(X), _cuda(X1), _cuda(frames), _cuda(canon), sync_errors=True).cpu().numpy()
-    np.testing.assert_array_equal(again, fused)
+    for b in range(Bt):
+        np.testing.assert_array_equal(again[:frames[b], b], fused[:frames[b], b])
 
 
 def test_fused_batches_full_size_and_reference_golden():

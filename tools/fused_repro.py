@@ -1,0 +1,44 @@
+"""Diagnostic: run-to-run differences of mdd_forward_fused in the exact-fp32 mode (which stage diverges first, valid rows only)."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np, torch
+from ctc_attention_mispronunciation_amd import synth
+from ctc_attention_mispronunciation_amd.hip_model import HipModel
+prec = sys.argv[1] if len(sys.argv) > 1 else "f32"
+geom = synth.Geometry(**synth.REFERENCE)
+sd = synth.synth_state_dict(geom, seed=1234)
+shapes = [(5, 120, 9), (3, 64, 4), (7, 100, 12), (2, 120, 12), (4, 30, 1)]
+rs = np.random.Generator(np.random.PCG64(7))
+Bt, Tm, Lm = sum(s[0] for s in shapes), max(s[1] for s in shapes), max(s[2] for s in shapes)
+X = np.zeros((Bt, Tm, geom.feat), dtype=np.float32); X1 = np.zeros((Bt, Lm), dtype=np.int64)
+frames, canon = np.zeros(Bt, dtype=np.int32), np.zeros(Bt, dtype=np.int32)
+r = 0
+for (b, T, L) in shapes:
+    X[r:r + b, :T] = rs.standard_normal((b, T, geom.feat)).astype(np.float32); X1[r:r + b, :L] = rs.integers(2, 44, size=(b, L))
+    frames[r:r + b] = T // 2; canon[r:r + b] = L; r += b
+m = HipModel(geom, sd, precision=prec, taps=True)
+names = ["conv1", "rnn0", "rnn1", "rnn2", "rnn3", "text", "key"]
+def run():
+    lp = m.forward_fused(torch.from_numpy(X).cuda(), torch.from_numpy(X1).cuda(), torch.from_numpy(frames).cuda(), torch.from_numpy(canon).cuda(), sync_errors=True).cpu().numpy()
+    taps = {n: m.tap(n).cpu().numpy() for n in names}
+    taps["logp"] = lp
+    return taps
+def valid_mask(name, arr):
+    if name in ("text", "key"):
+        a = arr.reshape(Lm, Bt, -1); mk = np.zeros((Lm, Bt), bool)
+        for b in range(Bt): mk[:canon[b], b] = True
+    else:
+        a = arr.reshape(Tm // 2, Bt, -1); mk = np.zeros((Tm // 2, Bt), bool)
+        for b in range(Bt): mk[:frames[b], b] = True
+    return a, mk
+ref = run()
+for it in range(1, 8):
+    cur = run()
+    line = []
+    for n in names + ["logp"]:
+        a, mk = valid_mask(n, cur[n]); b_, _ = valid_mask(n, ref[n])
+        d = np.abs(a - b_)[mk]
+        bad = np.argwhere((np.abs(a - b_) > 0) & mk[..., None])
+        line.append("%s:%s" % (n, "ok" if not (d > 0).any() else "DIFF max %.1e n=%d first(t,b,u)=%s" % (d.max(), (d > 0).sum(), tuple(bad[0]))))
+    print("run %d vs run 0 (%s): " % (it, prec) + "  ".join(line))

@@ -26,7 +26,7 @@ def main():
     wt, wc = per_kernel(wd, "WRITE_SIZE")
     out = {}
     for k in rt:
-        if not k.startswith(("gemm", "lstm", "conv", "stack", "embed", "attn", "beam", "greedy")):
+        if not k.startswith(("gemm", "lstm", "conv", "stack", "embed", "attn", "beam", "greedy", "split")):
             continue
         out[k] = {"hbm_read_bytes_per_launch": int(2 * 1024 * rt[k] / rc[k]),
                   "hbm_write_bytes_per_launch": int(1024 * wt[k] / max(wc[k], 1)),

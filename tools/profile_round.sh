@@ -20,6 +20,7 @@ rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/${TAG}_pmc
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/${TAG}_pmc_write -o ${TAG} -- python3 $R/bench.py --steps 16 --warmup 8 $LEAN --no-roofline > /dev/null 2> $OUT/${TAG}_pmc_write.err
 python3 $R/tools/pmc_traffic.py $OUT/${TAG}_pmc_fetch $OUT/${TAG}_pmc_write "bench.py --steps 16 --warmup 8 (B=512 per pass)" > $OUT/${TAG}_pmc_traffic.json
 stats bf16x3 --precision bf16x3 --steps 64 --warmup 16 $LEAN
+stats f32mfma --precision f32 --steps 32 --warmup 8 $LEAN
 stats ctc --workload ctc256 --steps 50 --warmup 5
 stats train --workload train32 --steps 5 --warmup 2
 stats trainx3 --workload train32 --train-precision bf16x3 --steps 5 --warmup 2
