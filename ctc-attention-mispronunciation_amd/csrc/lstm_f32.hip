@@ -273,11 +273,10 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_f32_kernel(PersistArgs a) {
                 store_out(bt, t);
             }
             FSTAMP(4);
-            // ---- the next phase's panel: every wave answers for the pieces it fetched itself.  Always a full vmcnt(0) in front of
-            // the check: a counted wait (the split-bf16 kernel's vmcnt(K) past the younger stores) let the check read chunks
-            // whose first words had landed and whose last had not -- run-to-run differences with one tile per team, found by
-            // test_fused_batches_of_different_lengths_equal_their_own_runs -- and the store acknowledgements it would skip
-            // (~1 us) arrive before a panel requested right after the publish can be fresh (~2 us) anyway.
+            // ---- the next phase's panel: every wave answers for the pieces it fetched itself.  A plain vmcnt(0) in front of every check
+            // (not the split-bf16 kernel's counted vmcnt(K) past the younger stores): the store acknowledgements it also waits for
+            // (~1 us) arrive before a panel requested right after the publish can be fresh (~2 us) anyway, and the check then never
+            // reads LDS with a transfer of its own still in flight.
             if (stale) {
                 long long t0 = 0;
                 int polls = 0;
