@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmdd_hip.so")
+LIB_PATH = os.environ.get("MDD_LIB_PATH") or os.path.join(_HERE, "libmdd_hip.so")   # (MDD_LIB_PATH: a diagnostic build of the same library, tests only)
 
 MDD_ERR_EMPTY = -5   # include/mdd_hip.h: an empty sequence where the reference raises TypeError
 

@@ -326,6 +326,40 @@ int init_lstm_attributes() {
 __device__ __forceinline__ void mfma_a(f32x4 &acc, const bf16x8 &a_agpr, const bf16x8 &b) {
     asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc) : "a"(a_agpr), "v"(b));
 }
+// The other two products of a k-step in the same form.  ALL MFMAs of the persistent kernels' product loops are asm volatile, so that
+// their issue order is the source order (product-major: a k-step's three products over the RTW row tiles, i.e. an accumulator is
+// written again RTW >= 2 MFMAs later), whatever the scheduler does around them.  Round 2 mixed builtin MFMAs with the asm one: the
+// compiler cannot see that an asm MFMA reads its accumulator, inserts no wait state in front of it, and -- once the
+// __builtin_amdgcn_sched_barrier calls that happened to pin the product-major order were removed -- scheduled
+//     v_mfma a[152:155], v[98:101], v[182:185], 0 ; v_mfma a[152:155], a[96:99], v[178:181], a[152:155]
+// back to back: the second read a[152:155] before the first had written it, and results moved by 1.7e-4 (profiles/round3_lstm_ordering.txt).
+// The sched barriers are a speed hint now (MDD_NO_SCHED_HINT builds give identical bits).  The accumulators' readers after the loop
+// are vector instructions the compiler cannot order behind an asm MFMA either: mfma_drain() supplies their wait states.
+__device__ __forceinline__ void mfma_v(f32x4 &acc, const bf16x8 &a, const bf16x8 &b) {
+    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
+}
+__device__ __forceinline__ void mfma_v0(f32x4 &acc, const bf16x8 &a, const bf16x8 &b) {   // first product of a tile: from a literal zero
+    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=a"(acc) : "v"(a), "v"(b));
+}
+__device__ __forceinline__ void mfma_drain() { asm volatile("s_nop 7\n\ts_nop 7" ::: "memory"); }
+// The B operands of a k-step are made by vector instructions (tag masks, register moves) just before its MFMAs.  "VALU writes a VGPR ->
+// MFMA reads it" needs two wait states, which the compiler supplies for builtin MFMAs and cannot for asm ones (the first all-asm build was
+// wrong in the 1-, 3- and 4-tile forms, whose schedules put a v_and directly in front of the first MFMA): this statement takes both
+// operands as read-write, so every instruction that produces them sits in front of it, and its s_nop 1 is the two wait states.
+// The A fragments of the k-step go through it too: under register pressure (three and four tiles) the compiler parks some of the "resident"
+// VGPR fragments in the accumulation file and copies them back (v_accvgpr_read = a VALU write) right in front of their MFMA.
+// tools/check_mfma_hazards.py scans the built ISA for exactly these patterns (tests/test_host.py::test_asm_mfma_hazards).
+template <int N>
+__device__ __forceinline__ void mfma_operands_ready(bf16x8 &bh, bf16x8 &bl, bf16x8 (&a)[N]) {
+    static_assert(N == 2 || N == 3, "row tiles per wave");
+    if (N == 3) asm volatile("s_nop 1" : "+v"(bh), "+v"(bl), "+v"(a[0]), "+v"(a[1]), "+v"(a[2]));
+    else asm volatile("s_nop 1" : "+v"(bh), "+v"(bl), "+v"(a[0]), "+v"(a[1]));
+}
+#ifdef MDD_NO_SCHED_HINT
+#define MDD_SCHED_HINT() do { } while (0)
+#else
+#define MDD_SCHED_HINT() __builtin_amdgcn_sched_barrier(0)
+#endif
 
 // ---- persistent layer kernel, data-tagged hand-off ("the data IS the flag", Guideline 16 form R2).
 // Same team structure, but (1) a team is 8 workgroups (32 teams = 2 directions x 16 batch groups), each workgroup
@@ -552,7 +586,7 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_granule_kernel(PersistArgs 
                 // first: nothing slow may be younger than the sweep request (see the counted wait at its consumption).
                 const bool early = PF != 0 && a.early && ns < T;
                 if (early) { request_sweep(nbt, ns, pb ^ 1); requested = true; }
-                const bool do_gx = s + 1 < T, do_rq = PF == 2 && ns < T && !early;
+                const bool do_rq = PF == 2 && ns < T && !early;
                 const int tt_next = d ? max(T - 2 - s, 0) : min(s + 1, T - 1);   // the step whose slab this phase requests
                 // The MFMA operands come straight from the travelling chunks (no unpacking pass, no second copy in LDS): per
                 // k-step two 16-byte chunks {hi x4 | lo' x4} -> the hi halves of both are one operand, the lo halves (tag
@@ -572,7 +606,7 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_granule_kernel(PersistArgs 
                         rb[p] = *reinterpret_cast<const u32x4 *>(fb + p * 2048 + 256);
                     }
                     unsigned sraw = 0, smask = 0;                     // sums of the lo words with / without their tag bits
-                    __builtin_amdgcn_sched_barrier(0);
+                    MDD_SCHED_HINT();
 #pragma unroll
                     for (int ks = 0; ks < KS; ks++) {
                         const u32x4 xa = ra[ks % PD], xb = rb[ks % PD];
@@ -584,28 +618,33 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_granule_kernel(PersistArgs 
                         hq[0] = xa[0]; hq[1] = xa[1]; hq[2] = xb[0]; hq[3] = xb[1];
                         lq[0] = xa[2] & 0xfffefffeu; lq[1] = xa[3] & 0xfffefffeu; lq[2] = xb[2] & 0xfffefffeu; lq[3] = xb[3] & 0xfffefffeu;
                         if (PF != 0) { sraw += xa[2] + xb[2]; smask += lq[0] + lq[2]; }   // one tagged word per 16-byte chunk: a chunk is one lane's single store
-                        const bf16x8 bh = __builtin_bit_cast(bf16x8, hq), bl = __builtin_bit_cast(bf16x8, lq);
-                        // One and two tiles: the slab pieces are issued unconditionally (a branch per k-step costs the loop more than the
-                        // piece: -2.6 % on the product section): at the last step they fetch a valid slab nobody reads, in a redo they fetch
-                        // the same slab again.  (Three and four tiles keep the guarded form: their sweep pieces share these k-steps.)
-                        if (PF != 2) { if (ks < NGX) load_gx(bt, (s + 1) & 1, tt_next, ks, ks + 1); }
-                        else if (tries == 0) {
-                            if (ks < NGX) { if (do_gx) load_gx(bt, (s + 1) & 1, tt_next, ks, ks + 1); }
-                            else if (ks < NGX + NLD) { if (do_rq) request_sweep(nbt, ns, pb ^ 1, ks - NGX, ks - NGX + 1); }
-                        }
+                        bf16x8 bh = __builtin_bit_cast(bf16x8, hq), bl = __builtin_bit_cast(bf16x8, lq);
+                        // The slab pieces are issued unconditionally (a branch per k-step costs the loop more than the piece: -2.6 % on the
+                        // product section): at the last step they fetch a valid slab nobody reads, in a redo they fetch the same slab again.
+                        // (Round 2 kept a guard around them in the three- and four-tile forms because lifting it changed last bits there: that
+                        // was the hidden-hazard class described at mfma_v() -- another code shape, another schedule around the asm MFMA --
+                        // not the request itself; with the hazards expressed the bits stay.)  The sweep pieces of the three- and four-tile
+                        // forms stay conditional: after a redo, or with no next phase, there is nothing to request.
+                        if (ks < NGX) load_gx(bt, (s + 1) & 1, tt_next, ks, ks + 1);
+                        else if (PF == 2 && tries == 0 && ks < NGX + NLD) { if (do_rq) request_sweep(nbt, ns, pb ^ 1, ks - NGX, ks - NGX + 1); }
                         // product-major order: consecutive MFMAs hit different accumulators (no dependent-issue stall);
                         // each accumulator still sees ah.bl, al.bh, ah.bh in that order (bit-identical to the step kernel)
                         // (the scheduler would otherwise regroup them per accumulator into dependent back-to-back pairs)
+                        bf16x8 ak[RTW];
 #pragma unroll
-                        for (int rt = 0; rt < RTW; rt++)   // the first product of a tile starts from a literal zero: no accumulator clearing per phase (or per redo)
-                            acc[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[rt][ks], bl, ks == 0 ? (f32x4){0.f, 0.f, 0.f, 0.f} : acc[rt], 0, 0, 0);
-                        __builtin_amdgcn_sched_barrier(0);
+                        for (int rt = 0; rt < RTW; rt++) ak[rt] = ah[rt][ks];
+                        mfma_operands_ready(bh, bl, ak);
+#pragma unroll
+                        for (int rt = 0; rt < RTW; rt++) {   // the first product of a tile starts from a literal zero: no accumulator clearing per phase (or per redo)
+                            if (ks == 0) mfma_v0(acc[rt], ak[rt], bl); else mfma_v(acc[rt], ak[rt], bl);
+                        }
+                        MDD_SCHED_HINT();
 #pragma unroll
                         for (int rt = 0; rt < RTW; rt++) mfma_a(acc[rt], al[rt][ks], bh);   // lo fragments stay in AGPRs and feed the MFMA from there
-                        __builtin_amdgcn_sched_barrier(0);
+                        MDD_SCHED_HINT();
 #pragma unroll
-                        for (int rt = 0; rt < RTW; rt++) acc[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[rt][ks], bh, acc[rt], 0, 0, 0);
-                        __builtin_amdgcn_sched_barrier(0);
+                        for (int rt = 0; rt < RTW; rt++) mfma_v(acc[rt], ak[rt], bh);
+                        MDD_SCHED_HINT();
                     }
                     const unsigned tsum = sraw - smask;
                     static_assert(NGX + NLD <= KS, "one LDS-DMA piece per k-step");
@@ -625,9 +664,9 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_granule_kernel(PersistArgs 
                 }
                 if (a.dbg && PF != 0) ph[5] += 1;
                 if (do_rq) requested = true;
-                int in_flight = PF != 2 ? NGX + ((early && !tries) ? NLD : 0)       // (a redo's vmcnt(0) came before its own slab pieces)
-                                        : (tries ? 0 : ((do_gx ? NGX : 0) + ((do_rq || early) ? NLD : 0)));
-                early_gx = (early && (PF != 2 || do_gx) && !tries) ? NGX : 0;       // memory instructions younger than an early request
+                int in_flight = NGX + (PF != 2 ? ((early && !tries) ? NLD : 0)      // (a redo's vmcnt(0) came before its own slab pieces)
+                                               : ((!tries && (do_rq || early)) ? NLD : 0));
+                early_gx = (early && !tries) ? NGX : 0;                             // memory instructions younger than an early request
                 if (PF == 1 && ns < T && !early) {   // two tiles: the other tile's panel has had the length of these MFMAs to arrive
                     request_sweep(nbt, ns, pb ^ 1); requested = true;
                     in_flight += NLD;
@@ -642,6 +681,7 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_granule_kernel(PersistArgs 
             const bool valid = lb < a.BGr && g * a.BGr + lb < B;
             float4 gv[RTW];
             float hn[RTW];
+            mfma_drain();                        // (the asm MFMAs' results are read by vector instructions from here on)
 #pragma unroll
             for (int rt = 0; rt < RTW; rt++)     // the slab reads together (one LDS round trip), each lane its own 16 bytes
                 gv[rt] = *reinterpret_cast<const float4 *>(Gx + (bt * 2 + (s & 1)) * GXT + ((wave * RTW + rt) * 64 + lane) * 4);
@@ -898,7 +938,7 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_granule_kernel(BwdPersistArgs
                 ra[p] = *reinterpret_cast<const u32x4 *>(rb_ + c * 16);
                 rb[p] = *reinterpret_cast<const u32x4 *>(rb_ + (c ^ 1) * 16);
             }
-            __builtin_amdgcn_sched_barrier(0);
+            MDD_SCHED_HINT();
 #pragma unroll
             for (int ks = 0; ks < KS; ks++) {
                 const u32x4 xa = ra[ks % PD], xb = rb[ks % PD];
@@ -910,18 +950,22 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_granule_kernel(BwdPersistArgs
                 u32x4 hq, lq;
                 hq[0] = xa[0]; hq[1] = xa[1]; hq[2] = xb[0]; hq[3] = xb[1];
                 lq[0] = xa[2] & 0xfffefffeu; lq[1] = xa[3] & 0xfffefffeu; lq[2] = xb[2] & 0xfffefffeu; lq[3] = xb[3] & 0xfffefffeu;
-                const bf16x8 bh = __builtin_bit_cast(bf16x8, hq), bl = __builtin_bit_cast(bf16x8, lq);
+                bf16x8 bh = __builtin_bit_cast(bf16x8, hq), bl = __builtin_bit_cast(bf16x8, lq);
+                bf16x8 ak[UT];
 #pragma unroll
-                for (int ut = 0; ut < UT; ut++)
-                    acc[ut] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[ut][ks], bl, ks == 0 ? (f32x4){0.f, 0.f, 0.f, 0.f} : acc[ut], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
+                for (int ut = 0; ut < UT; ut++) ak[ut] = ah[ut][ks];
+                mfma_operands_ready(bh, bl, ak);
+#pragma unroll
+                for (int ut = 0; ut < UT; ut++) { if (ks == 0) mfma_v0(acc[ut], ak[ut], bl); else mfma_v(acc[ut], ak[ut], bl); }
+                MDD_SCHED_HINT();
 #pragma unroll
                 for (int ut = 0; ut < UT; ut++) mfma_a(acc[ut], al[ut][ks], bh);
-                __builtin_amdgcn_sched_barrier(0);
+                MDD_SCHED_HINT();
 #pragma unroll
-                for (int ut = 0; ut < UT; ut++) acc[ut] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[ut][ks], bh, acc[ut], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
+                for (int ut = 0; ut < UT; ut++) mfma_v(acc[ut], ak[ut], bh);
+                MDD_SCHED_HINT();
             }
+            mfma_drain();
             // D layout: row (unit of the tile) = 4 * kq + r, column (batch row) = li
 #pragma unroll
             for (int ut = 0; ut < UT; ut++)

@@ -386,6 +386,48 @@ def test_gate_functions_accuracy():
     assert torch.isnan(s2).all() and torch.isnan(t2).all()
 
 
+def test_sched_hints_do_not_change_results():
+    """Round 2's finding: with the __builtin_amdgcn_sched_barrier calls removed from lstm_layer_granule_kernel its results moved (1.7e-4 on an
+    rnn tap).  Cause (profiles/round3_lstm_ordering.txt): a builtin MFMA followed back to back by an inline-asm MFMA on the same accumulator --
+    the compiler cannot see the asm one's read and inserts no wait state; the barriers happened to keep the product-major order that spaces
+    them.  All product-loop MFMAs are asm volatile now (issue order = source order), so the barriers are a speed hint only: the library's
+    twin built WITHOUT them (libmdd_hip_nohint.so, `make nohint`) must give the bits of the library itself -- reference geometry golden
+    shape, one to four row tiles per team (B = 100, 512, 700, 1000), H = 384 and 256, the training variant's forward included."""
+    import subprocess
+    import sys
+    from tests.helpers import ROOT
+    twin = os.path.join(ROOT, "ctc-attention-mispronunciation_amd", "libmdd_hip_nohint.so")
+    assert os.path.exists(twin), "build it with `make -C ctc-attention-mispronunciation_amd/csrc nohint` (__graft_entry__.build() does)"
+    code = r"""
+import sys, hashlib, numpy as np, torch
+sys.path.insert(0, %r)
+from ctc_attention_mispronunciation_amd import synth
+from ctc_attention_mispronunciation_amd.hip_model import HipModel
+out = []
+for H in (384, 256):
+    geom = synth.Geometry(**dict(synth.REFERENCE, hidden=H))
+    sd = synth.synth_state_dict(geom, seed=77)
+    for B in (100, 512, 700, 1000):
+        x, x1, _, _ = synth.synth_batch(geom, B=B, T=40, L=6, seed=B, ragged=True)
+        m = HipModel(geom, sd, precision="bf16x3", taps=True)
+        lp = m.forward(torch.from_numpy(x).cuda(), torch.from_numpy(x1).cuda(), sync_errors=True).cpu().numpy()
+        h = hashlib.sha256(lp.tobytes())
+        for n in ("rnn0", "rnn1", "rnn2", "rnn3", "text"):
+            h.update(m.tap(n).cpu().numpy().tobytes())
+        out.append(h.hexdigest())
+print("DIGEST " + " ".join(out))
+""" % ROOT
+    digests = []
+    for lib in (None, twin):
+        env = dict(os.environ)
+        if lib:
+            env["MDD_LIB_PATH"] = lib
+        r = subprocess.run([sys.executable, "-c", code], env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        digests.append([l for l in r.stdout.splitlines() if l.startswith("DIGEST ")][-1])
+    assert digests[0] == digests[1], (digests[0], digests[1])
+
+
 @pytest.mark.parametrize("B", [512, 700])
 def test_persistent_lstm_stale_panel_redo_path(B, monkeypatch):
     """The BiLSTM uses a panel requested ahead without checking it first and redoes the tile's products when the tags

@@ -305,3 +305,29 @@ print("sanitized host entry points ok")
     env = dict(os.environ, LD_PRELOAD=asan, ASAN_OPTIONS="detect_leaks=0:abort_on_error=1", UBSAN_OPTIONS="halt_on_error=1")
     r = subprocess.run([sys.executable, "-c", child, lib, GOLD], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "sanitized host entry points ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+def test_asm_mfma_hazards(tmp_path):
+    """The kernels that issue MFMAs from inline asm (the persistent BiLSTM layers, the f32x6 GEMM) hide those instructions' register reads
+    from the compiler's hazard recognizer.  The gfx950 ISA of those translation units, rebuilt here, must be free of the two patterns that
+    produced silently wrong numbers (profiles/round3_lstm_ordering.txt): a vector instruction writing an MFMA operand fewer than two wait
+    states in front of the MFMA, and dependent MFMAs issued back to back (tools/check_mfma_hazards.py)."""
+    import shutil
+    import subprocess
+    import sys
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc on this machine")
+    csrc = os.path.join(ROOT, "ctc-attention-mispronunciation_amd", "csrc")
+    procs = []
+    for unit, pat in (("lstm", ["granule"]), ("lstm_f32", ["layer_f32"]), ("gemm_bf16x6", ["f32x6"])):
+        out = str(tmp_path / (unit + ".s"))
+        procs.append((unit, pat, out, subprocess.Popen([hipcc, "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-ffp-contract=off", "-Wno-unused-result",
+                                                        "-Wno-inline-asm", "--offload-device-only", "-S", "-o", out, os.path.join(csrc, unit + ".hip")],
+                                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+    for unit, pat, out, pr in procs:
+        log = pr.communicate(timeout=900)[0]
+        assert pr.returncode == 0, log[-2000:]
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_mfma_hazards.py"), out] + pat, capture_output=True, text=True)
+        assert r.returncode == 0 and " 0 finding(s)" in r.stdout, unit + ":\n" + r.stdout[:3000]
+        assert not r.stdout.startswith("0 kernel(s)"), unit
