@@ -179,7 +179,9 @@ __global__ __launch_bounds__(256, 1) void gemm_f32x6_kernel(const unsigned short
     auto ktile = [&](int kt, bf16x8 (&fac)[X6_RT][3], bf16x8 (&fan)[X6_RT][3]) {
         const unsigned char *st = smem6 + (kt % X6_NS) * X6_STAGE;
         const unsigned nst = (unsigned)(((kt + 1) % X6_NS) * X6_STAGE);
-        const bool more = kt + 1 < nk;
+        // (the last K-tile requests itself again instead of nothing: a branch in front of each of the 15 memory instructions cost more than
+        // one K-tile's worth of redundant, never-read loads per 61)
+        const int ktn = min(kt + 1, nk - 1);
         bf16x8 fw[2][3][2];
 #pragma unroll
         for (int p = 0; p < 3; p++)
@@ -194,10 +196,10 @@ __global__ __launch_bounds__(256, 1) void gemm_f32x6_kernel(const unsigned short
                     for (int jj = 0; jj < 2; jj++) fw[(jp + 1) & 1][p][jj] = x6_frag(st + p * X6_PW, ((jp + 1) * 2 + jj) * 16 + l16, kq16);
             }
             // memory instructions of the next K-tile, one per product group: 9 A fragment loads (pairs 0, 1), 6 W pieces (pairs 1, 2)
-#define X6_MEM(g_) do { if (more) { const int s_ = jp * 6 + (g_); \
+#define X6_MEM(g_) do { const int s_ = jp * 6 + (g_); \
                 if (s_ < 9) { const int p_ = s_ / X6_RT, i_ = s_ % X6_RT; \
-                    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(fan[i_][p_]) : "v"(aoff[i_]), "s"(Ap + (size_t)p_ * a_plane + (size_t)(kt + 1) * M * 32) : "memory"); } \
-                else if (s_ < 9 + X6_NPW) piece(s_ - 9, kt + 1, nst); } } while (0)
+                    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(fan[i_][p_]) : "v"(aoff[i_]), "s"(Ap + (size_t)p_ * a_plane + (size_t)ktn * M * 32) : "memory"); } \
+                else if (s_ < 9 + X6_NPW) piece(s_ - 9, ktn, nst); } while (0)
 #define X6_GROUP(acc_, wp_, ap_) _Pragma("unroll") for (int i = 0; i < X6_RT; i++) { _Pragma("unroll") for (int jj = 0; jj < 2; jj++) X6_MFMA(acc_[i][jp * 2 + jj], fw[jp & 1][wp_][jj], fac[i][ap_]); }
             X6_MEM(0); X6_GROUP(sm, 1, 1)      // mid . mid
             X6_MEM(1); X6_GROUP(sm, 2, 0)      // W lo . A hi
