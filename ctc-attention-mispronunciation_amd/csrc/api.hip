@@ -64,6 +64,8 @@ struct mdd_model {
     std::vector<mdd::SplitPtr> wih_s, whh_s;                // split-bf16 copies of the GEMM / recurrent weights
     std::vector<unsigned short *> wih_3;                    // three-plane (f32x6) copies of the input-projection weights, K-tile-major
     unsigned short *t_wih_3 = nullptr, *w_conv1_3 = nullptr; // (conv1 weights [co][kh][kw][ci] as three row-major planes)
+    std::vector<unsigned short *> whh_3;                    // Whh' [3][2][4H][H]: three row-major planes of the recurrent weights (f32x6 layer kernel)
+    unsigned short *t_whh_3 = nullptr;
     mdd::SplitPtr t_whh_s{nullptr, nullptr};
     mdd::SplitPtr t_wih_s{nullptr, nullptr}, w_score_s{nullptr, nullptr}, w_conv1_s{nullptr, nullptr};
     std::vector<void *> owned;  // every hipMalloc'd weight pointer
@@ -92,6 +94,8 @@ struct mdd_model {
     // one persistent launch per BiLSTM layer: the split-bf16 teams (lstm.hip) in mode 1, the exact-fp32 teams (lstm_f32.hip) in mode 0
     bool persist(int B) const { return lstm_persist && !lstm_x3 && packed_h() && B <= granule_max_b && (x3() || lstm_persist_f32); }
     bool lstm_persist_f32 = true;
+    bool lstm_persist_x6 = true;     // MDD_LSTM_X6=0: mode 2 runs the exact-fp32 layer kernel instead (diagnostic)
+    bool lx6(int B) const { return x6() && lstm_persist_x6 && persist(B) && B <= mdd::lstm_x6_max_b(cfg.hidden); }   // the f32x6 recurrence (lstm_x6.hip)
     bool x6() const {   // f32x6: the time-batched input projections on the bf16 matrix cores with three planes per operand; all else as mode 0
         return precision == 2 && rnn_in() % 32 == 0 && (2 * cfg.hidden) % 32 == 0 && cfg.emb_dim % 32 == 0;
     }
@@ -209,6 +213,22 @@ static void pack_whh(const std::vector<float> &w, int H, std::vector<float> &out
                             w[((size_t)d * 4 * H + ut * 16 + (lane & 15)) * H + 16 * j + 4 * (lane >> 4) + mm];
 }
 
+// fp32 matrix -> three bf16 planes (hi | mid | lo, same element order), on the device
+static int upload_split3(mdd_model *m, const std::vector<float> &w, unsigned short **out) {
+    const size_t n = w.size();
+    std::vector<unsigned short> buf(3 * n);
+    for (size_t i = 0; i < n; i++) {
+        buf[i] = host_bf16(w[i]);
+        const float r1 = w[i] - host_bf16_f32(buf[i]);
+        buf[n + i] = host_bf16(r1);
+        buf[2 * n + i] = host_bf16(r1 - host_bf16_f32(buf[n + i]));
+    }
+    MDD_HIP_CHECK(hipMalloc((void **)out, 3 * n * sizeof(unsigned short)));
+    m->owned.push_back(*out);
+    MDD_HIP_CHECK(hipMemcpy(*out, buf.data(), 3 * n * sizeof(unsigned short), hipMemcpyHostToDevice));
+    return MDD_OK;
+}
+
 // The forward as an ordered list of stages (one or more kernel launches each).  mdd_forward captures all
 // of them into one graph; mdd_forward_profile replays them one by one between HIP events.
 struct Stage { const char *name; int launches; double flops; };
@@ -276,6 +296,7 @@ static int run_stage(mdd_model *m, int si, const float *x, int B, int T, const i
         }
         if (m->persist(B)) {
             info->launches = 1;
+            if (m->lx6(B)) return launch_lstm_layer_x6(a, m->whh_3[n], reinterpret_cast<unsigned short *>(m->hx.p), m->sync_words, m->err_flag, st);
             return x3 ? launch_lstm_layer_granule(a, reinterpret_cast<unsigned short *>(m->hx.p), m->sync_words, m->err_flag, st)
                       : launch_lstm_layer_f32(a, reinterpret_cast<unsigned short *>(m->hx.p), m->sync_words, m->err_flag, st);
         }
@@ -308,6 +329,7 @@ static int run_stage(mdd_model *m, int si, const float *x, int B, int T, const i
         a.seqlen = m->llen;
         if (m->persist(B)) {
             info->launches = 1;
+            if (m->lx6(B)) return launch_lstm_layer_x6(a, m->t_whh_3, reinterpret_cast<unsigned short *>(m->hx.p), m->sync_words, m->err_flag, st);
             return x3 ? launch_lstm_layer_granule(a, reinterpret_cast<unsigned short *>(m->hx.p), m->sync_words, m->err_flag, st)
                       : launch_lstm_layer_f32(a, reinterpret_cast<unsigned short *>(m->hx.p), m->sync_words, m->err_flag, st);
         }
@@ -407,12 +429,15 @@ extern "C" int mdd_create(const mdd_config *cfg, int device, mdd_model **out) {
     if (int rc = init_lstm_attributes()) { delete m; return rc; }
     if (int rc = init_granule_attributes()) { delete m; return rc; }
     if (int rc = init_lstm_f32_attributes()) { delete m; return rc; }
+    if (int rc = init_lstm_x6_attributes()) { delete m; return rc; }
     if (int rc = init_conv_attributes()) { delete m; return rc; }
     if (int rc = init_gemm_attributes()) { delete m; return rc; }
     if (int rc = init_gemm_x6_attributes()) { delete m; return rc; }
     m->n_cu = prop.multiProcessorCount;
     if (!persistent_grid_fits(m->n_cu)) m->lstm_persist = false;   // per-step kernels instead (smaller partitions, other gfx950 SKUs)
     if (!persistent_f32_grid_fits(m->n_cu)) m->lstm_persist_f32 = false;
+    if (!persistent_x6_grid_fits(m->n_cu)) m->lstm_persist_x6 = false;
+    { const char *e6 = getenv("MDD_LSTM_X6"); if (e6 && e6[0] == '0') m->lstm_persist_x6 = false; }
     hipError_t e = hipMalloc((void **)&m->err_flag, sizeof(int));
     if (e == hipSuccess) e = hipMemset(m->err_flag, 0, sizeof(int));
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&m->cap_stream, hipStreamNonBlocking);
@@ -513,6 +538,7 @@ extern "C" int mdd_finalize_weights(mdd_model *m) {
         } else m->wih_3.push_back(nullptr);
         if (!pack_gate_rows(m, base, "weight_hh_l0", H, H, tmp)) return MDD_ERR_STATE;
         { SplitPtr sp{nullptr, nullptr}; if ((rc = upload_split(m, tmp, &sp))) return rc; m->whh_s.push_back(sp); }
+        { unsigned short *p3 = nullptr; if (use_packed(m) && (rc = upload_split3(m, tmp, &p3))) return rc; m->whh_3.push_back(p3); }
         if (use_packed(m)) { std::vector<float> pk; pack_whh(tmp, H, pk); tmp.swap(pk); }
         if ((rc = upload(m, tmp, &d))) return rc;
         m->whh.push_back(d);
@@ -535,6 +561,7 @@ extern "C" int mdd_finalize_weights(mdd_model *m) {
         }
         if (!pack_gate_rows(m, "lstm_embeds.", "weight_hh_l0", H, H, tmp)) return MDD_ERR_STATE;
         if ((rc = upload_split(m, tmp, &m->t_whh_s))) return rc;
+        if (use_packed(m) && (rc = upload_split3(m, tmp, &m->t_whh_3))) return rc;
         if (use_packed(m)) { std::vector<float> pk; pack_whh(tmp, H, pk); tmp.swap(pk); }
         if ((rc = upload(m, tmp, &m->t_whh))) return rc;
         std::vector<float> bi, bh;
@@ -623,7 +650,11 @@ static int forward_prepare(mdd_model *m, const float *x_dev, int32_t B, int32_t 
         const size_t need = (rows * kmax > trows * k2 ? rows * kmax : trows * k2) * 3 / 2 + 64;
         if (m->x6() && (rc = ensure(m->p3, need, zs))) return rc;
     }
-    if (m->persist(B) && (rc = ensure(m->hx, (size_t)2 * 32 * granule_bg(B) * H * 2 + 64 + 256 * 6 * 2, zs))) return rc;   // the exchange buffer of the persistent layers (u64 granules) + stamps
+    if (m->persist(B)) {   // the exchange buffer of the persistent layers (u64 granules; three bf16 planes per (parity, team, tile) in lstm_x6.hip) + stamps
+        size_t need = (size_t)2 * 32 * granule_bg(B) * H * 2;
+        if (m->lx6(B) && lstm_x6_hx_bytes(H, B) / 4 > need) need = lstm_x6_hx_bytes(H, B) / 4;
+        if ((rc = ensure(m->hx, need + 64 + 256 * 6 * 2, zs))) return rc;
+    }
     if (m->taps) {
         m->tap_rnn.resize(c.layers);
         for (int n = 0; n + 1 < c.layers; n++) if ((rc = ensure(m->tap_rnn[n], rows * 2 * H, zs))) return rc;
@@ -785,7 +816,7 @@ extern "C" const float *mdd_tap(mdd_model *m, const char *name, int64_t *numel) 
         p = dst.p;
     }
     else if (n == "lstm_dbg" && m->hx.p) {   // diagnostic stamps of the last persistent layer launch (MDD_LSTM_DBG=1)
-        p = m->hx.p + (size_t)2 * 32 * granule_bg(B) * m->cfg.hidden * 2;
+        p = m->hx.p + (m->lx6(B) ? lstm_x6_hx_bytes(m->cfg.hidden, B) / 4 : (size_t)2 * 32 * granule_bg(B) * m->cfg.hidden * 2);
         ne = 256 * 6 * 2;
     }
     else if (n == "conv1") { p = m->seq0.p; ne = (int64_t)Tp * B * m->rnn_in(); }

@@ -110,6 +110,12 @@ int launch_lstm_layer_granule(const LstmStepArgs &s, unsigned short *hx, unsigne
 int launch_lstm_layer_f32(const LstmStepArgs &s, unsigned short *hx, unsigned int *sync, int *err_flag, hipStream_t st);
 int init_lstm_f32_attributes();
 int persistent_f32_grid_fits(int n_cu);
+// f32x6 persistent layer (lstm_x6.hip): teams of 16, W_hh' as three row-major bf16 planes [3][2][4H][H], h exchanged as three bf16 planes; fp32 outputs
+int launch_lstm_layer_x6(const LstmStepArgs &s, const unsigned short *whh3, unsigned short *hx, unsigned int *sync, int *err_flag, hipStream_t st);
+int init_lstm_x6_attributes();
+int persistent_x6_grid_fits(int n_cu);
+size_t lstm_x6_hx_bytes(int H, int B);
+int lstm_x6_max_b(int H);
 // The backward recurrence of a layer in one launch (split-bf16 training variant, B <= 256, H in {256, 384}); hx: lstm_bwd_granule_hx_bytes(H)
 size_t lstm_bwd_granule_hx_bytes(int H);
 int launch_lstm_bwd_granule(const float *dout, const float *gates, const float *cst, SplitPtr whhT, float *dg, int T, int B, int H, unsigned short *hx,

@@ -307,6 +307,61 @@ def test_persistent_f32_lstm_full_length_and_poisoned_input(monkeypatch):
     np.testing.assert_array_equal(bad[:, keep], ref[:, keep])
 
 
+@pytest.mark.parametrize("H", [384, 256])
+@pytest.mark.parametrize("B", [1, 17, 100, 128, 129, 256, 300, 512, 513, 700, 1000, 1024])
+def test_persistent_x6_lstm_tracks_exact_fp32_recurrence(B, H, monkeypatch):
+    """The default mode's recurrence (lstm_layer_x6_kernel: W_hh' and h as three bf16 planes each, six products, teams of 16) in every
+    team geometry (1 to 8 row tiles per team), H = 384 and H = 256, beside the same mode run with the exact-fp32 layer kernel
+    (MDD_LSTM_X6=0; everything else identical): every layer's raw state within 4e-6 absolute (|h| <= 1; the products differ by
+    ~2^-24 relative per term and in summation order), the log-probs within 2e-5; ragged lengths exercise the reverse direction's
+    per-row start, and the padded frames of short rows are exact zeros in both.  Two runs of the x6 kernel are bit-identical."""
+    geom = synth.Geometry(**dict(synth.REFERENCE, hidden=H))
+    sd = synth.synth_state_dict(geom, seed=77)
+    x, x1, _, _ = synth.synth_batch(geom, B=B, T=40, L=6, seed=B, ragged=True)
+    monkeypatch.setenv("MDD_LSTM_X6", "0")
+    m0 = _hip().HipModel(geom, sd, precision="f32x6", taps=True)
+    ref = m0.forward(_cuda(x), _cuda(x1), sync_errors=True).cpu().numpy()
+    ref_taps = [m0.tap("rnn%d" % i).cpu().numpy() for i in range(4)] + [m0.tap("text").cpu().numpy()]
+    monkeypatch.delenv("MDD_LSTM_X6")
+    m1 = _hip().HipModel(geom, sd, precision="f32x6", taps=True)
+    got = m1.forward(_cuda(x), _cuda(x1), sync_errors=True).cpu().numpy()
+    worst = 0.0
+    for i, name in enumerate(["rnn0", "rnn1", "rnn2", "rnn3", "text"]):
+        t = m1.tap(name).cpu().numpy()
+        assert np.isfinite(t).all(), name
+        np.testing.assert_array_equal(t == 0, ref_taps[i] == 0, err_msg=name + ": zero pattern (padded frames)")
+        worst = max(worst, float(np.abs(t - ref_taps[i]).max()))
+        np.testing.assert_allclose(t, ref_taps[i], rtol=0, atol=4e-6, err_msg=name)
+    np.testing.assert_allclose(got, ref, rtol=0, atol=2e-5)
+    from tests.helpers import record_margin
+    record_margin("x6_recurrence_vs_exact_fp32_state[B=%d,H=%d]" % (B, H), worst, 4e-6)
+    again = m1.forward(_cuda(x), _cuda(x1), sync_errors=True).cpu().numpy()
+    np.testing.assert_array_equal(again, got)
+
+
+def test_persistent_x6_lstm_full_length_and_poisoned_input(monkeypatch):
+    """T' = 250 at the benchmarked batch (four row tiles per team) beside the exact-fp32 layer kernel; then one utterance gets a NaN
+    and an Inf frame: the launch neither stalls nor reports an error (a NaN state travels as 1.5, which keeps the tag bits valid),
+    and every other utterance's rows are bit-identical to the clean run."""
+    geom = synth.Geometry(**synth.REFERENCE)
+    sd = synth.synth_state_dict(geom, seed=79)
+    x, x1, _, _ = synth.synth_batch(geom, B=512, T=500, L=40, seed=3, ragged=False)
+    monkeypatch.setenv("MDD_LSTM_X6", "0")
+    ref = _hip().HipModel(geom, sd, precision="f32x6").forward(_cuda(x), _cuda(x1), sync_errors=True).cpu().numpy()
+    monkeypatch.delenv("MDD_LSTM_X6")
+    m = _hip().HipModel(geom, sd, precision="f32x6")
+    got = m.forward(_cuda(x), _cuda(x1), sync_errors=True).cpu().numpy()
+    np.testing.assert_allclose(got, ref, rtol=0, atol=5e-5)
+    from tests.helpers import record_margin
+    record_margin("x6_recurrence_vs_exact_fp32_logprobs[B=512,T'=250]", float(np.abs(got - ref).max()), 5e-5)
+    xb = x.copy()
+    xb[37, 100, 5] = np.nan
+    xb[37, 300, 7] = np.inf
+    bad = m.forward(_cuda(xb), _cuda(x1), sync_errors=True).cpu().numpy()
+    keep = [b for b in range(512) if b != 37]
+    np.testing.assert_array_equal(bad[:, keep], got[:, keep])
+
+
 def _gemm_modes_against_fp64(M, N, K, modes, seed=0):
     import ctypes as C
     from ctc_attention_mispronunciation_amd import _lib
