@@ -94,8 +94,14 @@ struct mdd_model {
     // one persistent launch per BiLSTM layer: the split-bf16 teams (lstm.hip) in mode 1, the exact-fp32 teams (lstm_f32.hip) in mode 0
     bool persist(int B) const { return lstm_persist && !lstm_x3 && packed_h() && B <= granule_max_b && (x3() || lstm_persist_f32); }
     bool lstm_persist_f32 = true;
-    bool lstm_persist_x6 = true;     // MDD_LSTM_X6=0: mode 2 runs the exact-fp32 layer kernel instead (diagnostic)
-    bool lx6(int B) const { return x6() && lstm_persist_x6 && persist(B) && B <= mdd::lstm_x6_max_b(cfg.hidden); }   // the f32x6 recurrence (lstm_x6.hip)
+    bool lstm_persist_x6 = true;     // MDD_LSTM_X6=0: mode 2 runs the exact-fp32 layer kernel instead (diagnostic); =force: lstm_x6.hip wherever it can run
+    bool lstm_x6_force = false;
+    // the f32x6 recurrence (lstm_x6.hip) where it is the faster of the two reference-width layer kernels (tools/lstm_kernel_choice.py,
+    // profiles/round3_lstm_x6_notes.txt): at H = 384 for every batch size (0.60 - 0.93 of the exact-fp32 kernel's time), at H = 256 up to
+    // 128 rows (0.83; beyond, the fp32 kernel's shorter products win: 1.07 - 1.5)
+    bool lx6(int B) const {
+        return x6() && lstm_persist_x6 && persist(B) && B <= mdd::lstm_x6_max_b(cfg.hidden) && (lstm_x6_force || cfg.hidden == 384 || B <= 128);
+    }
     bool x6() const {   // f32x6: the time-batched input projections on the bf16 matrix cores with three planes per operand; all else as mode 0
         return precision == 2 && rnn_in() % 32 == 0 && (2 * cfg.hidden) % 32 == 0 && cfg.emb_dim % 32 == 0;
     }
@@ -437,7 +443,7 @@ extern "C" int mdd_create(const mdd_config *cfg, int device, mdd_model **out) {
     if (!persistent_grid_fits(m->n_cu)) m->lstm_persist = false;   // per-step kernels instead (smaller partitions, other gfx950 SKUs)
     if (!persistent_f32_grid_fits(m->n_cu)) m->lstm_persist_f32 = false;
     if (!persistent_x6_grid_fits(m->n_cu)) m->lstm_persist_x6 = false;
-    { const char *e6 = getenv("MDD_LSTM_X6"); if (e6 && e6[0] == '0') m->lstm_persist_x6 = false; }
+    { const char *e6 = getenv("MDD_LSTM_X6"); if (e6 && e6[0] == '0') m->lstm_persist_x6 = false; if (e6 && e6[0] == 'f') m->lstm_x6_force = true; }
     hipError_t e = hipMalloc((void **)&m->err_flag, sizeof(int));
     if (e == hipSuccess) e = hipMemset(m->err_flag, 0, sizeof(int));
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&m->cap_stream, hipStreamNonBlocking);

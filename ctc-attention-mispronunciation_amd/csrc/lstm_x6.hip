@@ -130,8 +130,8 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_x6_kernel(X6Args a) {
     // it consumes itself in the cell update of the r-th row tile its wave owns
     const unsigned gx_lds = (unsigned)(unsigned long long)(lds_void_t *)Gx, rw_lds = (unsigned)(unsigned long long)(lds_void_t *)Rw;
     const int wv = __builtin_amdgcn_readfirstlane(wave);            // the wave's index as a scalar
-    auto load_gx = [&](int bt, int buf, int tt) {
-        const float *gbase = a.gx + (size_t)tt * B * 2 * 4 * H;
+    auto gx_at = [&](int tt) { return a.gx + (size_t)tt * B * 2 * 4 * H; };
+    auto load_gx = [&](int bt, int buf, const float *gbase) {
         const int b = min(g * a.BGr + min(bt * 16 + li, a.BGr - 1), B - 1);
 #pragma unroll
         for (int r = 0; r < 2; r++) {
@@ -320,18 +320,16 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_x6_kernel(X6Args a) {
             og_[2 * 16 * 8] = (unsigned short)(__builtin_bit_cast(unsigned short, b2) | tagw);
         }
     };
-    auto cell2 = [&](auto bt_, int sc, bool on, bool adv) {
+    // (the step's addresses come in as pointers worked out once per step: gxn = the gx slab of the tile's next step, hxpub = the team's
+    // panels of the step's parity, outp / rawp = the layer outputs' slabs of the step's time index)
+    auto cell2 = [&](auto bt_, const float *gxn, unsigned char *hxpub, float *outp, float *rawp, bool on) {
         constexpr int bt = decltype(bt_)::value;
-        const int t = d ? (T - 1 - sc) : sc;
-        if (NBT >= 2) {   // this tile's next slab, into the buffer part 1 has read (needed a round from now); `adv` false (no previous tile yet): the slab that is there, again
-            const int scn = adv ? sc + 1 : sc;
-            load_gx(bt, 0, d ? max(T - 1 - scn, 0) : min(scn, T - 1));
-        }
+        if (NBT >= 2) load_gx(bt, 0, gxn);   // this tile's next slab, into the buffer part 1 has read (needed a round from now)
         // the stores come last in the phase: the wait at its end, s_waitcnt vmcnt(3), then covers every transfer into LDS (vector memory
         // operations return in order) without waiting for the write-through store's acknowledgement (~1 us)
         {
             const int prow = lane & 15, pp = lane >> 4;              // lane -> (plane, batch row): 48 lanes
-            const __amdgpu_buffer_rsrc_t drs = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char *>(hx_parity(sc)) + (size_t)bt * tbytes, 0, (int)tbytes, 0x00020000);
+            const __amdgpu_buffer_rsrc_t drs = __builtin_amdgcn_make_buffer_rsrc(hxpub + (size_t)bt * tbytes, 0, (int)tbytes, 0x00020000);
             const u32x4 pv = *reinterpret_cast<const u32x4 *>(Og + widx * (3 * 16 * 8) + ((pp < 3 ? pp : 0) * 16 + prow) * 8);
             const unsigned off = (pp < 3 && on) ? (unsigned)(pp * PLB + ((member * CPM + (ot0 >> 1)) * 16 + prow) * 16) : 0xffffffffu;
             __builtin_amdgcn_raw_buffer_store_b128(pv, drs, off, 0, 16 /* sc1 */);
@@ -344,10 +342,10 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_x6_kernel(X6Args a) {
             const unsigned el = (unsigned)((g * a.BGr + bt * 16 + rr) * 2 * H + d * H + member * UW + rt * 4);
             const int lo = rr * UW + rt * 4;
             const u32x4 v = *reinterpret_cast<const u32x4 *>(Os + lo);
-            const __amdgpu_buffer_rsrc_t rs_ = __builtin_amdgcn_make_buffer_rsrc(out_main + (size_t)t * slab, 0, (int)(slab * 4), 0x00020000);
+            const __amdgpu_buffer_rsrc_t rs_ = __builtin_amdgcn_make_buffer_rsrc(outp, 0, (int)(slab * 4), 0x00020000);
             __builtin_amdgcn_raw_buffer_store_b128(v, rs_, mine ? el * 4u : 0xffffffffu, 0, 0);
             const u32x4 v2 = *reinterpret_cast<const u32x4 *>(Or + lo);
-            const __amdgpu_buffer_rsrc_t rs2 = __builtin_amdgcn_make_buffer_rsrc((two_out ? a.out_raw : out_main) + (size_t)t * slab, 0, (int)(slab * 4), 0x00020000);
+            const __amdgpu_buffer_rsrc_t rs2 = __builtin_amdgcn_make_buffer_rsrc(rawp, 0, (int)(slab * 4), 0x00020000);
             __builtin_amdgcn_raw_buffer_store_b128(v2, rs2, (mine && two_out) ? el * 4u : 0xffffffffu, 0, 0);
         }
     };
@@ -361,7 +359,7 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_x6_kernel(X6Args a) {
         // step 0 multiplies an all-zero panel (exact zeros out): both panel buffers start as zeros
 #pragma unroll
         for (int i = 0; i < 2 * NLD; i++) *reinterpret_cast<u32x4 *>(Rw + (size_t)(i * NTH + tid) * 16) = (u32x4){0u, 0u, 0u, 0u};
-        if constexpr (OWNER) x6_static_for<NBT>([&](auto bt_) { load_gx(decltype(bt_)::value, 0, d ? (T - 1) : 0); });
+        if constexpr (OWNER) x6_static_for<NBT>([&](auto bt_) { load_gx(decltype(bt_)::value, 0, gx_at(d ? (T - 1) : 0)); });
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         lds_barrier();
         f32x4 gP[NT];                                                // SKEW: the sums of the previous phase, waiting for their cell update
@@ -369,14 +367,21 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_x6_kernel(X6Args a) {
         for (int t = 0; t < NT; t++) gP[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
         int pc = 0;
         bool dead = false;
+        float *const raw_main = two_out ? a.out_raw : out_main;
+        auto t_of = [&](int st) { return d ? (T - 1 - st) : st; };
         for (int s = 0; s < T && !dead; s++) {
+            // the step's addresses (and the previous step's, which the skewed schedule's first tile still works on)
+            const int sp_ = max(s - 1, 0), sn_ = min(s + 1, T - 1);
+            const float *const gx_s = gx_at(t_of(s)), *const gx_n = gx_at(t_of(sn_));
+            float *const out_s = out_main + (size_t)t_of(s) * slab, *const out_p = out_main + (size_t)t_of(sp_) * slab;
+            float *const raw_s = raw_main + (size_t)t_of(s) * slab, *const raw_p = raw_main + (size_t)t_of(sp_) * slab;
+            unsigned char *const hx_s = const_cast<unsigned char *>(hx_parity(s)), *const hx_p = const_cast<unsigned char *>(hx_parity(s - 1));
             auto phase = [&](auto bt_) {
                 constexpr int bt = decltype(bt_)::value;
                 constexpr int nbt = bt + 1 < NBT ? bt + 1 : 0, pbt = bt > 0 ? bt - 1 : NBT - 1;
                 const int ns = bt + 1 < NBT ? s : s + 1, psv = bt > 0 ? s : s - 1;
                 const int pb = pc & 1;
                 ++pc;
-                const int tt_next = d ? max(T - 2 - s, 0) : min(s + 1, T - 1);
                 f32x4 gs[NT];
                 if (NBT == 1) {
                     // one tile per team: the panel is the team's own state of a moment ago -- fetched (again and again) until it is whole
@@ -385,13 +390,13 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_x6_kernel(X6Args a) {
                         if (!ensure_fresh(bt, s - 1, pb)) { dead = true; return; }
                     }
                     XSTAMP(0);
-                    products(std::false_type{}, pb, 0u, gs, [&](int j) { if (OWNER && j == 0) load_gx(bt, (s + 1) & 1, tt_next); });
+                    products(std::false_type{}, pb, 0u, gs, [&](int j) { if (OWNER && j == 0) load_gx(bt, (s + 1) & 1, gx_n); });
                     XSTAMP(1);
                     send_partials(role_, gs, 0);
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the gx slab
                     lds_barrier();                                      // the partial sums
                     XSTAMP(2);
-                    if constexpr (OWNER) { cell1(role_, gs, 0, bt_, s, true); XSTAMP(3); cell2(bt_, s, true, true); }
+                    if constexpr (OWNER) { cell1(role_, gs, 0, bt_, s, true); XSTAMP(3); cell2(bt_, gx_n, hx_s, out_s, raw_s, true); }
                     XSTAMP(4);
                     return;
                 }
@@ -399,22 +404,24 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_x6_kernel(X6Args a) {
                 // the previous phase's cell update, publish and output stores run inside the loop.  Two tiles: the next panel's state was published
                 // at the end of the phase before -- requested when the product loop ends, it travels during the cell update.
                 constexpr int RQJ = SKEW ? 0 : KH - 1;
-                for (bool first = true;; first = false) {
-                    const bool stale = products(chk_, pb, tag_word(s + 2), gs, [&](int j) {   // (s - 1) % 3 == (s + 2) % 3, s >= 0
-                        if (j == RQJ) request_sweep(hx_parity(ns - 1), nbt, pb ^ 1);   // (step -1 = parity 1 before anything was published there: zeros, as step 0 wants them)
-                        if constexpr (SKEW && OWNER) {
-                            if (j == 0) cell1(role_, gP, (pc & 1), std::integral_constant<int, pbt>{}, max(psv, 0), psv >= 0 && first);
-                            if (j == 1) cell2(std::integral_constant<int, pbt>{}, max(psv, 0), psv >= 0 && first, psv >= 0);
-                        }
-                    }) && s >= 1;
-                    XSTAMP(1);
-                    send_partials(role_, gs, (pc & 1) ^ 1);
-                    if constexpr (SKEW) { if constexpr (OWNER) wait_vmcnt(3); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }   // the next panel's pieces and the next gx slab: all but cell2()'s three stores
-                    const bool redo = wg_any(stale);                    // the barrier (SKEW: the next panel is whole; this phase's panel buffer is free again)
-                    XSTAMP(2);
-                    if (!redo) break;
+                const bool stale = products(chk_, pb, tag_word(s + 2), gs, [&](int j) {   // (s - 1) % 3 == (s + 2) % 3, s >= 0
+                    if (j == RQJ) request_sweep(hx_parity(ns - 1), nbt, pb ^ 1);   // (step -1 = parity 1 before anything was published there: zeros, as step 0 wants them)
+                    if constexpr (SKEW && OWNER) {
+                        if (j == 0) cell1(role_, gP, (pc & 1), std::integral_constant<int, pbt>{}, max(psv, 0), psv >= 0);
+                        if (j == 1) { if (bt > 0) cell2(std::integral_constant<int, pbt>{}, gx_n, hx_s, out_s, raw_s, true); else cell2(std::integral_constant<int, pbt>{}, gx_s, hx_p, out_p, raw_p, psv >= 0); }
+                    }
+                }) && s >= 1;
+                XSTAMP(1);
+                send_partials(role_, gs, (pc & 1) ^ 1);
+                if constexpr (SKEW) { if constexpr (OWNER) wait_vmcnt(3); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }   // the next panel's pieces and the next gx slab: all but cell2()'s three stores
+                const bool redo = wg_any(stale);                        // the barrier (SKEW: the next panel is whole; this phase's panel buffer is free again)
+                XSTAMP(2);
+                if (redo) {   // (rare) a granule of this phase's panel had not arrived: fetch the panel until it is whole, multiply again
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     if (!ensure_fresh(bt, s - 1, pb)) { dead = true; return; }
+                    products(std::false_type{}, pb, 0u, gs, [](int) {});
+                    send_partials(role_, gs, (pc & 1) ^ 1);
+                    lds_barrier();                                      // the partial sums are in place; the panel buffer may be the target of the next phase's request
                     if (DBG) ph[5] += 1000;
                 }
                 if (SKEW) {
@@ -425,7 +432,7 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_x6_kernel(X6Args a) {
                     XSTAMP(3);
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the next panel's pieces (travelling since the product loop ended) -- before the publish, whose acknowledgement takes longer
                     lds_barrier();
-                    if constexpr (OWNER) cell2(bt_, s, true, true);
+                    if constexpr (OWNER) cell2(bt_, gx_n, hx_s, out_s, raw_s, true);
                     XSTAMP(4);
                 }
                 XSTAMP(0);
@@ -435,7 +442,7 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_x6_kernel(X6Args a) {
         if constexpr (SKEW && OWNER) {   // the last phase's cell update (its partial sums were sent before the last barrier)
             if (!dead) {
                 cell1(role_, gP, (pc & 1) ^ 1, std::integral_constant<int, NBT - 1>{}, T - 1, true);
-                cell2(std::integral_constant<int, NBT - 1>{}, T - 1, true, true);
+                cell2(std::integral_constant<int, NBT - 1>{}, gx_at(t_of(T - 1)), const_cast<unsigned char *>(hx_parity(T - 1)), out_main + (size_t)t_of(T - 1) * slab, raw_main + (size_t)t_of(T - 1) * slab, true);
             }
         }
     };

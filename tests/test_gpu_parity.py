@@ -312,8 +312,8 @@ def test_persistent_f32_lstm_full_length_and_poisoned_input(monkeypatch):
 def test_persistent_x6_lstm_tracks_exact_fp32_recurrence(B, H, monkeypatch):
     """The default mode's recurrence (lstm_layer_x6_kernel: W_hh' and h as three bf16 planes each, six products, teams of 16) in every
     team geometry (1 to 8 row tiles per team), H = 384 and H = 256, beside the same mode run with the exact-fp32 layer kernel
-    (MDD_LSTM_X6=0; everything else identical): every layer's raw state within 4e-6 absolute (|h| <= 1; the products differ by
-    ~2^-24 relative per term and in summation order), the log-probs within 2e-5; ragged lengths exercise the reverse direction's
+    (MDD_LSTM_X6=0; everything else identical): every layer's raw state within 1e-6 absolute (|h| <= 1; the products differ by
+    ~2^-24 relative per term and in summation order; measured 2.4e-7), the log-probs within 1e-5; ragged lengths exercise the reverse direction's
     per-row start, and the padded frames of short rows are exact zeros in both.  Two runs of the x6 kernel are bit-identical."""
     geom = synth.Geometry(**dict(synth.REFERENCE, hidden=H))
     sd = synth.synth_state_dict(geom, seed=77)
@@ -322,7 +322,7 @@ def test_persistent_x6_lstm_tracks_exact_fp32_recurrence(B, H, monkeypatch):
     m0 = _hip().HipModel(geom, sd, precision="f32x6", taps=True)
     ref = m0.forward(_cuda(x), _cuda(x1), sync_errors=True).cpu().numpy()
     ref_taps = [m0.tap("rnn%d" % i).cpu().numpy() for i in range(4)] + [m0.tap("text").cpu().numpy()]
-    monkeypatch.delenv("MDD_LSTM_X6")
+    monkeypatch.setenv("MDD_LSTM_X6", "force")                  # (the library's own choice leaves H = 256 beyond 128 rows to the exact-fp32 kernel: it is the faster one there)
     m1 = _hip().HipModel(geom, sd, precision="f32x6", taps=True)
     got = m1.forward(_cuda(x), _cuda(x1), sync_errors=True).cpu().numpy()
     worst = 0.0
@@ -331,10 +331,10 @@ def test_persistent_x6_lstm_tracks_exact_fp32_recurrence(B, H, monkeypatch):
         assert np.isfinite(t).all(), name
         np.testing.assert_array_equal(t == 0, ref_taps[i] == 0, err_msg=name + ": zero pattern (padded frames)")
         worst = max(worst, float(np.abs(t - ref_taps[i]).max()))
-        np.testing.assert_allclose(t, ref_taps[i], rtol=0, atol=4e-6, err_msg=name)
-    np.testing.assert_allclose(got, ref, rtol=0, atol=2e-5)
+        np.testing.assert_allclose(t, ref_taps[i], rtol=0, atol=1e-6, err_msg=name)
+    np.testing.assert_allclose(got, ref, rtol=0, atol=1e-5)
     from tests.helpers import record_margin
-    record_margin("x6_recurrence_vs_exact_fp32_state[B=%d,H=%d]" % (B, H), worst, 4e-6)
+    record_margin("x6_recurrence_vs_exact_fp32_state[B=%d,H=%d]" % (B, H), worst, 1e-6)
     again = m1.forward(_cuda(x), _cuda(x1), sync_errors=True).cpu().numpy()
     np.testing.assert_array_equal(again, got)
 
