@@ -415,6 +415,8 @@ class DecodeJob(object):
             if name.startswith("lstm"):
                 if os.environ.get("MDD_LSTM") == "step" or B > 1024:
                     return "lstm_step_x3_kernel" if x3 else "lstm_step_packed_kernel"
+                if x6 and os.environ.get("MDD_LSTM_X6", "1")[0] != "0" and (self.geom.hidden == 384 and B <= 1024 or self.geom.hidden == 256 and B <= 128):
+                    return "lstm_layer_x6_kernel"      # mdd_model::lx6(): the f32x6 recurrence where it is the faster reference-width kernel
                 return "lstm_layer_granule_kernel" if x3 else "lstm_layer_f32_kernel"
             if name.startswith("gemm"):
                 if x6 and name.startswith(("gemm_ih", "gemm_text")):
@@ -431,8 +433,8 @@ class DecodeJob(object):
         cand = {k: v for k, v in groups.items() if k.startswith(("lstm_", "gemm_"))}
         kern = max(cand, key=lambda k: cand[k][0])
         ms, launches, flops = cand[kern]
-        bf16_kernel = kern in ("gemm_bf16x3_ph8_kernel", "gemm_bf16x3_glds_kernel", "lstm_layer_granule_kernel", "gemm_f32x6_kernel")
-        mult = 6 if kern == "gemm_f32x6_kernel" else (3 if bf16_kernel else 1)     # bf16 MFMA flops issued per algorithmic (fp32-equivalent) flop
+        bf16_kernel = kern in ("gemm_bf16x3_ph8_kernel", "gemm_bf16x3_glds_kernel", "lstm_layer_granule_kernel", "gemm_f32x6_kernel", "lstm_layer_x6_kernel")
+        mult = 6 if kern in ("gemm_f32x6_kernel", "lstm_layer_x6_kernel") else (3 if bf16_kernel else 1)     # bf16 MFMA flops issued per algorithmic (fp32-equivalent) flop
         peak = PEAK_BF16_MATRIX_TFLOPS if bf16_kernel else PEAK_F32_MATRIX_TFLOPS
         achieved = flops / (ms * 1e-3) / 1e12
         traffic = None
@@ -467,7 +469,7 @@ DTYPE_F32 = ("f32 -- reference width: every contraction of the model (conv0/conv
 DTYPE_X6 = ("f32 -- reference width (operands with all 24 significand bits, fp32 accumulate; see `accuracy`: closer to a float64 evaluation than "
             "ATen's own fp32): the large time-batched contractions (conv0/conv1, BiLSTM and text input projections) run on the bf16 matrix cores "
             "as f32x6 = each fp32 operand as three bf16 planes hi+mid+lo (exact), the six cross products down to 2^-24, hi.hi in its own "
-            "accumulator; the recurrent W_hh.h products, score / attention / classifier are exact fp32 MFMAs; gates / softmax fp32, beam "
+            "accumulator; so do the recurrent W_hh.h products (W_hh and the state h as three planes each; lstm_layer_x6_kernel); score / attention / classifier are exact fp32 MFMAs; gates / softmax fp32, beam "
             "scores f64")
 
 
