@@ -73,8 +73,10 @@ int mdd_finalize_weights(mdd_model *m);
  * 2 (default) = "f32x6": the large time-batched contractions -- conv0 / conv1 and the BiLSTM / text input projections -- on the bf16
  *     matrix cores with every fp32 operand carried as THREE bf16 planes (hi + mid + lo = its 24 significand bits exactly) and the six
  *     cross products down to 2^-24 of a product, fp32 accumulate, hi.hi in an accumulator of its own (gemm_bf16x6.hip: 6/16 of the cost
- *     of the fp32 MFMA, which on gfx950 runs at the fp32 vector rate); everything else as mode 0.  Needs contraction lengths that are
- *     multiples of 32 (falls back to 0 otherwise).
+ *     of the fp32 MFMA, which on gfx950 runs at the fp32 vector rate); so do the recurrent W_hh.h products where that is the faster of
+ *     the two reference-width layer kernels (lstm_x6.hip: W_hh and the state h as three planes each; H = 384 up to 1024 rows, H = 256
+ *     up to 128 rows; env MDD_LSTM_X6=0 / force); everything else as mode 0.  Needs contraction lengths that are multiples of 32 (falls
+ *     back to 0 otherwise).
  * 0 = every product an exact fp32 MFMA (v_mfma_f32_32x32x2_f32 in the time-batched GEMMs, v_mfma_f32_16x16x4_f32 in the recurrent
  *     W_hh.h products, the attention tail and the convolutions).
  * 1 = split-bf16 "x3" on v_mfma_f32_16x16x32_bf16: each fp32 operand = bf16 hi + bf16 lo (~16 significand bits), products hi.lo +
