@@ -45,6 +45,7 @@ struct X6Args {
     float *out, *out_raw;
     const float *oscale, *oshift;
     int T, B, BGr;                   // BGr: real rows per batch group (8 groups)
+    int force_mask;                  // diagnostic (MDD_X6_FORCE_REDO=n, a power of two): every n-th phase is declared stale, so that the refetch-and-multiply-again branch runs; -1: off
     long long *dbg;
     const int *seqlen;
 };
@@ -147,8 +148,12 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_x6_kernel(X6Args a) {
     constexpr int WQ = PANB / 4;                                     // bytes of a panel a wave copies
     static_assert(WQ == NLD * 1024 && NLD <= 12, "a wave's quarter is NLD whole pieces");
     auto request_sweep = [&](const unsigned char *hx_par, int bt, int pb) {
-        const unsigned char *b0 = hx_par + (size_t)bt * tbytes + (size_t)wv * WQ, *b1 = b0 + 4096, *b2 = b0 + 8192;
-        const unsigned la = rw_lds + (unsigned)(pb * PANB) + (unsigned)wv * (unsigned)WQ, v = (unsigned)lane * 16u;
+        // (wave-uniform by construction; said so explicitly: the assembly's operands must be scalar registers whatever the compiler's divergence analysis concludes)
+        const unsigned long long b0u = (unsigned long long)(hx_par + (size_t)bt * tbytes + (size_t)wv * WQ);
+        const unsigned char *b0 = reinterpret_cast<const unsigned char *>(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(b0u >> 32)) << 32) |
+                                                                    (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)b0u));   // (the builtin returns int: no sign extension)
+        const unsigned char *b1 = b0 + 4096, *b2 = b0 + 8192;
+        const unsigned la = __builtin_amdgcn_readfirstlane(rw_lds + (unsigned)(pb * PANB) + (unsigned)wv * (unsigned)WQ), v = (unsigned)lane * 16u;
 #define X6_G(B) "s_nop 0\n\tglobal_load_lds_dwordx4 %0, " B " sc1\n\tglobal_load_lds_dwordx4 %0, " B " offset:1024 sc1\n\t"
 #define X6_G2(B) "global_load_lds_dwordx4 %0, " B " offset:2048 sc1\n\tglobal_load_lds_dwordx4 %0, " B " offset:3072 sc1\n\t"
         if (NLD == 9)
@@ -184,6 +189,15 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_x6_kernel(X6Args a) {
         fk = nx;
         return r;
     };
+    // the same in two halves, for a verdict that is only read in the next phase: post() before the phase's barrier, posted() after it
+    int vslot = 0;
+    auto post = [&](bool v) { if (__any(v) && lane == 0) s_flag[fk] = 1; };
+    auto posted = [&] {
+        vslot = fk;
+        const int nx = fk == 2 ? 0 : fk + 1, n2 = nx == 2 ? 0 : nx + 1;
+        if (tid == 0) s_flag[n2] = 0;
+        fk = nx;
+    };
     // fetch the panel of (tile bt, step sp) into Rw[pb] until every granule carries the step's tag; false: gave up (abort flag / 200 ms)
     auto ensure_fresh = [&](int bt, int sp, int pb) -> bool {
         long long t0 = 0;
@@ -216,7 +230,7 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_x6_kernel(X6Args a) {
     // front of its own; CHK: the tag words of the whole panel are compared with the tag `e` of the step the panel should hold (this
     // wave's half as its fragments pass, the other half's tag words read for the purpose).  Per tile two chains: hh = Wh.hh and
     // sm = the five smaller products, smallest first; on return g[t] = hh + sm, this wave's partial sum of tile t.
-    auto products = [&](auto chk_, int pb, unsigned e, f32x4 *gsum, auto &&at_ks) -> bool {
+    auto products = [&](auto chk_, int pb, unsigned e, f32x4 *gsum, auto &&at_ks, auto &&pre) -> bool {
         constexpr bool CHK = decltype(chk_)::value;
         const unsigned char *fb = Rw + (size_t)pb * PANB + kq * 256 + li * 16 + kh * (KH * 1024);
         unsigned orall = 0u, andall = ~0u;
@@ -236,6 +250,7 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_x6_kernel(X6Args a) {
         u32x4 fh[3][3];
 #pragma unroll
         for (int p = 0; p < 3; p++) { fh[0][p] = *reinterpret_cast<const u32x4 *>(fb + p * PLB); fh[1][p] = *reinterpret_cast<const u32x4 *>(fb + p * PLB + 1024); }
+        pre();   // (the skewed schedule reads the previous phase's verdict here: its LDS round trip hides behind the fragment reads just issued)
 #pragma unroll
         for (int p = 0; p < 3; p++) {
             if (CHK) { orall |= fh[0][p][0]; andall &= fh[0][p][0]; }
@@ -366,7 +381,15 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_x6_kernel(X6Args a) {
 #pragma unroll
         for (int t = 0; t < NT; t++) gP[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
         int pc = 0;
-        bool dead = false;
+        bool dead = false, have_v = false;
+        auto redo = [&](int btv, int sv, int pbv, int pxb) {   // the products of (tile btv, step sv) again, from a panel fetched until it is whole: gP and Px[pxb]
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (!ensure_fresh(btv, sv - 1, pbv)) { dead = true; return; }
+            products(std::false_type{}, pbv, 0u, gP, [](int) {}, [] {});
+            send_partials(role_, gP, pxb);
+            lds_barrier();                                              // the partial sums are in place
+            if (DBG) ph[5] += 1000;
+        };
         float *const raw_main = two_out ? a.out_raw : out_main;
         auto t_of = [&](int st) { return d ? (T - 1 - st) : st; };
         for (int s = 0; s < T && !dead; s++) {
@@ -390,7 +413,7 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_x6_kernel(X6Args a) {
                         if (!ensure_fresh(bt, s - 1, pb)) { dead = true; return; }
                     }
                     XSTAMP(0);
-                    products(std::false_type{}, pb, 0u, gs, [&](int j) { if (OWNER && j == 0) load_gx(bt, (s + 1) & 1, gx_n); });
+                    products(std::false_type{}, pb, 0u, gs, [&](int j) { if (OWNER && j == 0) load_gx(bt, (s + 1) & 1, gx_n); }, [] {});
                     XSTAMP(1);
                     send_partials(role_, gs, 0);
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the gx slab
@@ -410,19 +433,32 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_x6_kernel(X6Args a) {
                         if (j == 0) cell1(role_, gP, (pc & 1), std::integral_constant<int, pbt>{}, max(psv, 0), psv >= 0);
                         if (j == 1) { if (bt > 0) cell2(std::integral_constant<int, pbt>{}, gx_n, hx_s, out_s, raw_s, true); else cell2(std::integral_constant<int, pbt>{}, gx_s, hx_p, out_p, raw_p, psv >= 0); }
                     }
+                }, [&] {
+                    // SKEW: was the previous phase's panel whole?  (rare: no -- a granule had not arrived: the panel is fetched until it is, that
+                    // tile's products are computed again; its cell update has not begun, the request that reuses its panel buffer not been sent)
+                    if constexpr (SKEW) { if (have_v && s_flag[vslot] != 0) redo(pbt, psv, pb ^ 1, pc & 1); }
                 }) && s >= 1;
+                const bool forced = a.force_mask >= 0 && s >= 1 && (pc & a.force_mask) == 0;
                 XSTAMP(1);
                 send_partials(role_, gs, (pc & 1) ^ 1);
-                if constexpr (SKEW) { if constexpr (OWNER) wait_vmcnt(3); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }   // the next panel's pieces and the next gx slab: all but cell2()'s three stores
-                const bool redo = wg_any(stale);                        // the barrier (SKEW: the next panel is whole; this phase's panel buffer is free again)
-                XSTAMP(2);
-                if (redo) {   // (rare) a granule of this phase's panel had not arrived: fetch the panel until it is whole, multiply again
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    if (!ensure_fresh(bt, s - 1, pb)) { dead = true; return; }
-                    products(std::false_type{}, pb, 0u, gs, [](int) {});
-                    send_partials(role_, gs, (pc & 1) ^ 1);
-                    lds_barrier();                                      // the partial sums are in place; the panel buffer may be the target of the next phase's request
-                    if (DBG) ph[5] += 1000;
+                if constexpr (SKEW) {
+                    post(stale || forced);
+                    if constexpr (OWNER) wait_vmcnt(3); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the next panel's pieces and the next gx slab: all but cell2()'s three stores
+                    lds_barrier();                                      // the next panel is whole; this phase's panel buffer is free again; the partial sums are in place
+                    posted();
+                    have_v = true;
+                    XSTAMP(2);
+                } else {
+                    const bool again = wg_any(stale || forced);         // the barrier
+                    XSTAMP(2);
+                    if (again) {   // (rare) a granule of this phase's panel had not arrived: fetch the panel until it is whole, multiply again
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        if (!ensure_fresh(bt, s - 1, pb)) { dead = true; return; }
+                        products(std::false_type{}, pb, 0u, gs, [](int) {}, [] {});
+                        send_partials(role_, gs, (pc & 1) ^ 1);
+                        lds_barrier();                                  // the partial sums are in place; the panel buffer may be the target of the next phase's request
+                        if (DBG) ph[5] += 1000;
+                    }
                 }
                 if (SKEW) {
 #pragma unroll
@@ -439,10 +475,13 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_x6_kernel(X6Args a) {
             };
             x6_static_for<NBT>([&](auto bt_) { if (!dead) phase(bt_); });
         }
-        if constexpr (SKEW && OWNER) {   // the last phase's cell update (its partial sums were sent before the last barrier)
-            if (!dead) {
-                cell1(role_, gP, (pc & 1) ^ 1, std::integral_constant<int, NBT - 1>{}, T - 1, true);
-                cell2(std::integral_constant<int, NBT - 1>{}, gx_at(t_of(T - 1)), const_cast<unsigned char *>(hx_parity(T - 1)), out_main + (size_t)t_of(T - 1) * slab, raw_main + (size_t)t_of(T - 1) * slab, true);
+        if constexpr (SKEW) {   // the last phase's verdict and cell update (its partial sums were sent before the last barrier)
+            if (!dead && have_v && s_flag[vslot] != 0) redo(NBT - 1, T - 1, (pc & 1) ^ 1, (pc & 1) ^ 1);
+            if constexpr (OWNER) {
+                if (!dead) {
+                    cell1(role_, gP, (pc & 1) ^ 1, std::integral_constant<int, NBT - 1>{}, T - 1, true);
+                    cell2(std::integral_constant<int, NBT - 1>{}, gx_at(t_of(T - 1)), const_cast<unsigned char *>(hx_parity(T - 1)), out_main + (size_t)t_of(T - 1) * slab, raw_main + (size_t)t_of(T - 1) * slab, true);
+                }
             }
         }
     };
@@ -497,6 +536,7 @@ int launch_lstm_layer_x6(const LstmStepArgs &s, const unsigned short *whh3, unsi
     a.gx = s.gx; a.whh3 = whh3; a.hx = hx; a.sync = sync; a.err_flag = err_flag;
     a.out = s.out; a.out_raw = s.out_raw; a.oscale = s.oscale; a.oshift = s.oscale ? s.oshift : nullptr;
     a.T = s.T; a.B = s.B; a.BGr = (s.B + 7) / 8; a.seqlen = s.seqlen;
+    { const char *fr = getenv("MDD_X6_FORCE_REDO"); const int n = fr ? atoi(fr) : 0; a.force_mask = (n > 0 && (n & (n - 1)) == 0) ? n - 1 : -1; }
     const int nbt = (a.BGr + 15) / 16;
     a.dbg = (getenv("MDD_LSTM_DBG") && s.T > 100) ? reinterpret_cast<long long *>(reinterpret_cast<unsigned char *>(hx) + lstm_x6_hx_bytes(s.H, s.B)) : nullptr;
     if (s.out_split.hi || s.gates_save || (!a.out && !a.out_raw) || !whh3) { set_error("persistent x6 lstm: fp32 outputs, inference only"); return MDD_ERR_ARG; }

@@ -339,6 +339,20 @@ def test_persistent_x6_lstm_tracks_exact_fp32_recurrence(B, H, monkeypatch):
     np.testing.assert_array_equal(again, got)
 
 
+@pytest.mark.parametrize("B", [256, 512, 640])
+def test_persistent_x6_lstm_redo_branch(B, monkeypatch):
+    """A panel whose granules have not all arrived is fetched again and the tile's products are recomputed -- a branch that real runs take
+    in < 0.1 % of the phases.  MDD_X6_FORCE_REDO=4 declares every fourth phase stale (two, four and five tiles per team: the plain and
+    the skewed schedule): the posteriors must not change by a bit."""
+    geom = synth.Geometry(**synth.REFERENCE)
+    sd = synth.synth_state_dict(geom, seed=81)
+    x, x1, _, _ = synth.synth_batch(geom, B=B, T=120, L=9, seed=B, ragged=True)
+    ref = _hip().HipModel(geom, sd, precision="f32x6").forward(_cuda(x), _cuda(x1), sync_errors=True).cpu().numpy()
+    monkeypatch.setenv("MDD_X6_FORCE_REDO", "4")
+    got = _hip().HipModel(geom, sd, precision="f32x6").forward(_cuda(x), _cuda(x1), sync_errors=True).cpu().numpy()
+    np.testing.assert_array_equal(got, ref)
+
+
 def test_persistent_x6_lstm_full_length_and_poisoned_input(monkeypatch):
     """T' = 250 at the benchmarked batch (four row tiles per team) beside the exact-fp32 layer kernel; then one utterance gets a NaN
     and an Inf frame: the launch neither stalls nor reports an error (a NaN state travels as 1.5, which keeps the tag bits valid),
