@@ -750,11 +750,29 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_granule_kernel(PersistArgs 
 int granule_bg(int B) { const int r = (B + 15) / 16; return (r + 15) / 16 * 16; }   // rows per batch group (16 groups), padded to whole tiles
 
 
+__global__ void zero_fill_kernel(u32x4 *p, size_t n16) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x) p[i] = (u32x4){0u, 0u, 0u, 0u};
+}
+// The persistent layer kernels need their exchange buffer's tags and their abort word zeroed before every launch.  Inside a captured graph a
+// hipMemsetAsync becomes a memset NODE, and replays of such graphs were measured to let a layer kernel start on the previous launch's
+// contents (tools/fused_repro3.py, exact-fp32 mode, small batches: the second and later mdd_forward_fused calls gave wrong layer-0 outputs,
+// up to 2e-2, in 7 of 12 and 4 of 14 processes; in none of 12 with MDD_GRAPH=0; in none of 14 with this kernel in the memset's place;
+// MDD_ZERO_BY_MEMSET=1 brings the memset nodes back for study).  A kernel node orders like every other kernel of the chain.
+int launch_zero_fill(void *p, size_t n, hipStream_t st) {
+    static const bool by_memset = [] { const char *e = getenv("MDD_ZERO_BY_MEMSET"); return e && e[0] == '1'; }();
+    if (by_memset) { MDD_HIP_CHECK(hipMemsetAsync(p, 0, n, st)); return MDD_OK; }
+    const size_t n16 = n / 16;
+    const int blocks = (int)std::min<size_t>((n16 + 255) / 256, 2048);
+    hipLaunchKernelGGL(zero_fill_kernel, dim3(blocks > 0 ? blocks : 1), dim3(256), 0, st, reinterpret_cast<u32x4 *>(p), n16);
+    MDD_LAUNCH_CHECK();
+    return MDD_OK;
+}
+
 template <int H, int NBT, int RTW, bool TRAIN = false>
 static int launch_granule_t(PersistArgs a, hipStream_t st) {
     const size_t smem = (size_t)16 * (H / 8) * 12 + (size_t)NBT * 2 * 16 * (H / 8) * 16 + (size_t)2 * 16 * H * 4;   // tiles (2 bf16 planes, fp32, tagged words) + gx slabs (2 parities) + two panel buffers
-    MDD_HIP_CHECK(hipMemsetAsync(a.sync, 0, 32 * sizeof(unsigned int), st));
-    MDD_HIP_CHECK(hipMemsetAsync(a.hx, 0, (size_t)2 * 32 * NBT * 16 * H * 4, st));   // tags must start at 0 on every launch
+    if (int rc = launch_zero_fill(a.sync, 32 * sizeof(unsigned int), st)) return rc;
+    if (int rc = launch_zero_fill(a.hx, (size_t)2 * 32 * NBT * 16 * H * 4, st)) return rc;   // tags must start at 0 on every launch
     hipLaunchKernelGGL((lstm_layer_granule_kernel<H, NBT, RTW, TRAIN>), dim3(kPersistGrid), dim3(256), smem, st, a);
     MDD_LAUNCH_CHECK();
     return MDD_OK;
@@ -1010,8 +1028,8 @@ template <int H>
 static int launch_bwd_granule_t(const BwdPersistArgs &a, hipStream_t st) {
     constexpr size_t panb = (size_t)16 * 4 * H * 4;
     const size_t smem = panb + (size_t)4 * (H / 8) * 16 * 4;
-    MDD_HIP_CHECK(hipMemsetAsync(a.sync, 0, 32 * sizeof(unsigned int), st));
-    MDD_HIP_CHECK(hipMemsetAsync(a.hx, 0, (size_t)2 * 32 * panb, st));   // tags must start at 0 on every launch
+    if (int rc = launch_zero_fill(a.sync, 32 * sizeof(unsigned int), st)) return rc;
+    if (int rc = launch_zero_fill(a.hx, (size_t)2 * 32 * panb, st)) return rc;   // tags must start at 0 on every launch
     hipLaunchKernelGGL((lstm_bwd_granule_kernel<H>), dim3(256), dim3(256), smem, st, a);
     MDD_LAUNCH_CHECK();
     return MDD_OK;

@@ -307,8 +307,8 @@ __global__ __launch_bounds__(256, 1) void lstm_layer_f32_kernel(PersistArgs a) {
 template <int H, int NBT, bool DBG = false>
 static int launch_f32_t(PersistArgs a, hipStream_t st) {
     const size_t smem = (size_t)16 * (H / 8) * 12 + (size_t)NBT * 2 * 16 * (H / 8) * 16 + (size_t)2 * 16 * H * 4;   // tiles + gx slabs (2 parities) + two panel buffers
-    MDD_HIP_CHECK(hipMemsetAsync(a.sync, 0, 32 * sizeof(unsigned int), st));
-    MDD_HIP_CHECK(hipMemsetAsync(a.hx, 0, (size_t)2 * 32 * NBT * 16 * H * 4, st));   // tags must start at 0 on every launch
+    if (int rc = launch_zero_fill(a.sync, 32 * sizeof(unsigned int), st)) return rc;
+    if (int rc = launch_zero_fill(a.hx, (size_t)2 * 32 * NBT * 16 * H * 4, st)) return rc;   // tags must start at 0 on every launch (by a kernel: lstm.hip)
     hipLaunchKernelGGL((lstm_layer_f32_kernel<H, NBT, DBG>), dim3(kPersistGrid), dim3(256), smem, st, a);
     MDD_LAUNCH_CHECK();
     return MDD_OK;

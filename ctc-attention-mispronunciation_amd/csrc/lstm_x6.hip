@@ -504,8 +504,8 @@ size_t lstm_x6_hx_bytes(int H, int B) {
 
 template <int H, int NBT, bool DBG = false>
 static int launch_x6_t(const X6Args &a, hipStream_t st) {
-    MDD_HIP_CHECK(hipMemsetAsync(a.sync, 0, 32 * sizeof(unsigned int), st));
-    MDD_HIP_CHECK(hipMemsetAsync(a.hx, 0, (size_t)2 * 16 * NBT * 3 * (H / 8) * 256, st));   // tags must start at 0 on every launch
+    if (int rc = launch_zero_fill(a.sync, 32 * sizeof(unsigned int), st)) return rc;
+    if (int rc = launch_zero_fill(a.hx, (size_t)2 * 16 * NBT * 3 * (H / 8) * 256, st)) return rc;   // tags must start at 0 on every launch (by a kernel: lstm.hip)
     hipLaunchKernelGGL((lstm_layer_x6_kernel<H, NBT, DBG>), dim3(kPersistGrid), dim3(256), x6_smem(H, NBT), st, a);
     MDD_LAUNCH_CHECK();
     return MDD_OK;

@@ -107,6 +107,8 @@ int persistent_grid_fits(int n_cu);   // 1 when all 256 workgroups of a persiste
 // data-tagged variant (8-workgroup teams, no counter): hx = 2*32*granule_bg(B)*H u64 granules (+ stamps), sync: 32 uints
 int launch_lstm_layer_granule(const LstmStepArgs &s, unsigned short *hx, unsigned int *sync, int *err_flag, hipStream_t st);
 // Exact-fp32 persistent layer (lstm_f32.hip): same teams / exchange buffer; W_hh in the packed layout (LstmStepArgs::packed), fp32 outputs
+// zero fill by a kernel (n a multiple of 16; see its definition in lstm.hip for why not hipMemsetAsync)
+int launch_zero_fill(void *p, size_t n, hipStream_t st);
 int launch_lstm_layer_f32(const LstmStepArgs &s, unsigned short *hx, unsigned int *sync, int *err_flag, hipStream_t st);
 int init_lstm_f32_attributes();
 int persistent_f32_grid_fits(int n_cu);

@@ -17,6 +17,14 @@ r = 0
 for (b, T, L) in shapes:
     X[r:r + b, :T] = rs.standard_normal((b, T, geom.feat)).astype(np.float32); X1[r:r + b, :L] = rs.integers(2, 44, size=(b, L))
     frames[r:r + b] = T // 2; canon[r:r + b] = L; r += b
+# MDD_REPRO_SHUFFLE=seed: vary the device address layout (allocations of random sizes kept alive; a few models created and dropped first)
+_keep = []
+if os.environ.get("MDD_REPRO_SHUFFLE"):
+    rr = np.random.Generator(np.random.PCG64(int(os.environ["MDD_REPRO_SHUFFLE"])))
+    for _ in range(int(rr.integers(1, 12))):
+        _keep.append(torch.empty(int(rr.integers(1 << 10, 1 << 28)), dtype=torch.uint8, device="cuda"))
+    for _ in range(int(rr.integers(0, 3))):
+        HipModel(geom, sd, precision=prec).forward(torch.from_numpy(X[:3, :64]).cuda(), torch.from_numpy(X1[:3, :4]).cuda(), sync_errors=True)
 m = HipModel(geom, sd, precision=prec, taps=True)
 names = ["conv1", "rnn0", "rnn1", "rnn2", "rnn3", "text", "key"]
 def run():
