@@ -118,29 +118,30 @@ __device__ __forceinline__ bf16x8 x6_frag(const unsigned char *plane, int row, i
 template <bool STAMP>
 __global__ __launch_bounds__(256, 1) void gemm_f32x6_kernel(const unsigned short *__restrict__ Ap, const unsigned short *__restrict__ Wp, size_t a_plane, size_t w_plane,
                                                             const float *__restrict__ bias, float *__restrict__ C, int M, int N, int K, int ldc, int tiles_n,
-                                                            long long *stamps) {
+                                                            int ntiles, long long *stamps) {
     // STAMP (diagnostic instantiation): per wave, cycles of the K loop in the MFMA stream / waiting for memory / at the barrier
     // -> stamps[(workgroup * 4 + wave) * 4 + {0, 1, 2}] (tools/gemm_time.py)
     long long sacc[4] = {0, 0, 0, 0}, stt = 0;
 #define X6_T(i_) do { if (STAMP) { const long long n_ = (long long)__builtin_readcyclecounter(); sacc[i_] += n_ - stt; stt = n_; } } while (0)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem6[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    int nwg = gridDim.x, bid = blockIdx.x;
-    int q = nwg >> 3, rem = nwg & 7, xcd = bid & 7;
-    int swz = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + (bid >> 3);   // an XCD walks consecutive tiles: the A panel stays in its L2
-    const int tm = swz / tiles_n, tn = swz % tiles_n;
-    const int m0 = tm * X6_BM + wave * (16 * X6_RT), n0 = tn * X6_BN;      // this wave's first row; the workgroup's first column
+    // PERSISTENT: a workgroup walks the tiles vb = blockIdx.x, + gridDim.x, ... (one workgroup per CU: no dispatch between tiles, and the next
+    // tile's first operands are requested before this tile's epilogue).  Tile of a virtual block index: an XCD (vb % 8) walks consecutive
+    // tiles, so that the A panel stays in its L2.
+    const int tq = ntiles >> 3, trem = ntiles & 7;
+    auto tile_of = [&](int vb, int &m0_, int &n0_) {
+        const int xcd = vb & 7;
+        const int swz = (xcd < trem ? xcd * (tq + 1) : trem * (tq + 1) + (xcd - trem) * tq) + (vb >> 3);
+        const int tm = swz / tiles_n, tn = swz % tiles_n;
+        m0_ = tm * X6_BM + wave * (16 * X6_RT); n0_ = tn * X6_BN;  // this wave's first row; the workgroup's first column
+    };
+    int vb = blockIdx.x, m0, n0;
+    tile_of(vb, m0, n0);
     f32x4 hh[X6_RT][8], sm[X6_RT][8], tot[X6_RT][8];
-#pragma unroll
-    for (int i = 0; i < X6_RT; i++)
-#pragma unroll
-        for (int j = 0; j < 8; j++) { hh[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; sm[i][j] = hh[i][j]; tot[i][j] = hh[i][j]; }
     const int l16 = lane & 15, kq = lane >> 4;
     // A fragments straight from the K-tile-major planes: lane (row l16 of row tile i, k-slice kq) reads 16 bytes at ((kt * M + row) * 32 + kq * 8)
     // elements; rows past M are clamped (their C rows are never stored)
     unsigned aoff[X6_RT];
-#pragma unroll
-    for (int i = 0; i < X6_RT; i++) aoff[i] = (unsigned)(((size_t)min(m0 + i * 16 + l16, M - 1) * 32 + kq * 8) * 2);
     auto load_a = [&](bf16x8 (&fa)[X6_RT][3], int kt) {
 #pragma unroll
         for (int p = 0; p < 3; p++) {
@@ -152,11 +153,16 @@ __global__ __launch_bounds__(256, 1) void gemm_f32x6_kernel(const unsigned short
     // W: LDS-DMA pieces of this wave = row groups 2w, 2w+1 (16 rows each) of the three planes
     const unsigned lds0 = (unsigned)(unsigned long long)(lds_void6 *)smem6;
     unsigned voffW[2];
+    auto set_tile = [&]() {   // the per-lane offsets of the tile at (m0, n0)
 #pragma unroll
-    for (int g = 0; g < 2; g++) {
-        const int row = (wave * 2 + g) * 16 + (lane >> 2), c = (lane & 3) ^ ((row >> 2) & 3);
-        voffW[g] = (unsigned)(((size_t)min(n0 + row, N - 1) * 32 + c * 8) * 2);
-    }
+        for (int i = 0; i < X6_RT; i++) aoff[i] = (unsigned)(((size_t)min(m0 + i * 16 + l16, M - 1) * 32 + kq * 8) * 2);
+#pragma unroll
+        for (int g = 0; g < 2; g++) {
+            const int row = (wave * 2 + g) * 16 + (lane >> 2), c = (lane & 3) ^ ((row >> 2) & 3);
+            voffW[g] = (unsigned)(((size_t)min(n0 + row, N - 1) * 32 + c * 8) * 2);
+        }
+    };
+    set_tile();
     auto piece = [&](int idx, int kt_, unsigned stage_off) {   // idx 0..5: plane idx / 2, row group idx % 2
         const int p = idx >> 1, g = idx & 1;
         const unsigned short *base = Wp + (size_t)p * w_plane + (size_t)kt_ * N * 32;
@@ -169,9 +175,6 @@ __global__ __launch_bounds__(256, 1) void gemm_f32x6_kernel(const unsigned short
 #pragma unroll
     for (int idx = 0; idx < X6_NPW; idx++) piece(idx, 0, 0u);
     load_a(faA, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_waitcnt(0x0F70);
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #define X6_MFMA(acc_, w_, a_) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc_) : "v"(w_), "v"(a_))
     // One K-tile: fac holds its A fragments, fan receives the next K-tile's.  Column tiles in pairs (jp): the pair's six W fragments are read
     // from LDS one pair ahead; per pair 3 rows x 2 columns x 6 products = 36 MFMAs, product-major (six different accumulators in a row),
@@ -221,6 +224,14 @@ __global__ __launch_bounds__(256, 1) void gemm_f32x6_kernel(const unsigned short
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // ... everybody's pieces; and every wave is done reading this stage
         X6_T(2);
     };
+    for (;;) {   // ---- one tile per iteration
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < X6_RT; i++)
+#pragma unroll
+        for (int j = 0; j < 8; j++) { hh[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; sm[i][j] = hh[i][j]; tot[i][j] = hh[i][j]; }
     if (STAMP) stt = (long long)__builtin_readcyclecounter();
     // Segments of X6_FLUSH K-tiles with the flush of hh into tot BETWEEN them; K-tiles in pairs, so that the two A fragment sets swap roles
     // without a register copy.
@@ -237,18 +248,25 @@ __global__ __launch_bounds__(256, 1) void gemm_f32x6_kernel(const unsigned short
 #pragma unroll
             for (int j = 0; j < 8; j++) { tot[i][j] += hh[i][j]; hh[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
     }
-#undef X6_MFMA
-    if (STAMP && stamps && lane == 0 && blockIdx.x < 1024)
-        for (int i = 0; i < 4; i++) stamps[((size_t)blockIdx.x * 4 + wave) * 4 + i] = sacc[i];
-#undef X6_T
+    // the next tile's first W stage and A fragments are requested before this tile's epilogue (stage 0 and faA are free: every wave has passed
+    // the last K-tile's barrier)
+    const int m0c = m0, n0c = n0, vbn = vb + (int)gridDim.x;
+    const bool more = vbn < ntiles;
+    if (more) {
+        tile_of(vbn, m0, n0);
+        set_tile();
+#pragma unroll
+        for (int idx = 0; idx < X6_NPW; idx++) piece(idx, 0, 0u);
+        load_a(faA, 0);
+    }
     asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
     const int q4 = kq * 4;   // D row = 4 * (lane >> 4) + r = C column, D col = lane & 15 = C row
 #pragma unroll
     for (int i = 0; i < X6_RT; i++) {
-        const int row = m0 + i * 16 + l16;
+        const int row = m0c + i * 16 + l16;
 #pragma unroll
         for (int j = 0; j < 8; j++) {
-            const int col = n0 + j * 16 + q4;
+            const int col = n0c + j * 16 + q4;
             if (row >= M || col >= N) continue;
             f32x4 v = tot[i][j] + sm[i][j];
             if (bias) { v[0] += bias[col]; if (col + 1 < N) v[1] += bias[col + 1]; if (col + 2 < N) v[2] += bias[col + 2]; if (col + 3 < N) v[3] += bias[col + 3]; }
@@ -257,6 +275,13 @@ __global__ __launch_bounds__(256, 1) void gemm_f32x6_kernel(const unsigned short
             else for (int r = 0; r < 4 && col + r < N; r++) dst[r] = v[r];
         }
     }
+    if (!more) break;
+    vb = vbn;
+    }   // ---- tiles
+#undef X6_MFMA
+    if (STAMP && stamps && lane == 0 && blockIdx.x < 1024)
+        for (int i = 0; i < 4; i++) stamps[((size_t)blockIdx.x * 4 + wave) * 4 + i] = sacc[i];
+#undef X6_T
 }
 
 int init_gemm_x6_attributes() {
@@ -272,10 +297,11 @@ int launch_gemm_f32x6(const unsigned short *A3, size_t a_plane, const unsigned s
         set_error("gemm_f32x6: bad shape M=%d N=%d K=%d ldc=%d", M, N, K, ldc);
         return MDD_ERR_ARG;
     }
-    const int tn = (N + X6_BN - 1) / X6_BN;
-    const dim3 grid(((M + X6_BM - 1) / X6_BM) * tn);
-    if (stamps) hipLaunchKernelGGL(gemm_f32x6_kernel<true>, grid, dim3(256), X6_NS * X6_STAGE, st, A3, W3, a_plane, w_plane, bias, C, M, N, K, ldc, tn, stamps);
-    else hipLaunchKernelGGL(gemm_f32x6_kernel<false>, grid, dim3(256), X6_NS * X6_STAGE, st, A3, W3, a_plane, w_plane, bias, C, M, N, K, ldc, tn, (long long *)nullptr);
+    const int tn = (N + X6_BN - 1) / X6_BN, ntiles = ((M + X6_BM - 1) / X6_BM) * tn;
+    static const int grid_cap = [] { const char *e = getenv("MDD_GEMM_X6_GRID"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 256; }();   // one persistent workgroup per CU
+    const dim3 grid(ntiles < grid_cap ? ntiles : grid_cap);
+    if (stamps) hipLaunchKernelGGL(gemm_f32x6_kernel<true>, grid, dim3(256), X6_NS * X6_STAGE, st, A3, W3, a_plane, w_plane, bias, C, M, N, K, ldc, tn, ntiles, stamps);
+    else hipLaunchKernelGGL(gemm_f32x6_kernel<false>, grid, dim3(256), X6_NS * X6_STAGE, st, A3, W3, a_plane, w_plane, bias, C, M, N, K, ldc, tn, ntiles, (long long *)nullptr);
     MDD_LAUNCH_CHECK();
     return MDD_OK;
 }
